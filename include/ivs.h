@@ -1,0 +1,121 @@
+/*
+ * ivs.h -- C ABI of the MI355X-native IV interpolation engine (libivs.so).
+ *
+ * This is the drop-in boundary for the reference hot path
+ *   /root/reference/src/interpolation/core.py:16-85  IVInterpolator.interpolate_symbol
+ * The reference has no FFI today (plain Python calling pandas); these entry points are
+ * what a ctypes binding inside that class binds (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C linkage, no exceptions, no torch types; every pointer is a DEVICE pointer
+ *     owned by the caller (e.g. torch tensor .data_ptr()) unless marked host;
+ *   - fp64, row-major, contiguous; NaN in a value array means "missing quote" (not a knot);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *   - no allocation, no synchronisation inside a call (safe to capture in a hipGraph);
+ *   - return 0 on success or a negative IVS_E* code; ivs_last_error() gives the text
+ *     (thread local).  Numerical conditions (too few knots) are reported per item in
+ *     the `status` array, never through the return code.
+ */
+#ifndef IVS_H
+#define IVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVS_ABI_VERSION 1
+
+/* interpolation methods: the pandas method names that core.py:61 forwards
+ * (`merged[col].interpolate(method=self.method)`) and that this engine implements */
+enum {
+    IVS_LINEAR      = 0, /* 'linear','index','values': np.interp; NaN left of the first knot, hold-last on the right */
+    IVS_CUBIC       = 1, /* 'cubic': interp1d(kind=3) = not-a-knot spline; NaN outside the hull; needs >= 4 knots */
+    IVS_CUBICSPLINE = 2, /* 'cubicspline': CubicSpline(not-a-knot); 2 knots = line, 3 = parabola; NaN left, extrapolates right */
+    IVS_SLINEAR     = 3  /* 'slinear': interp1d(kind=1); NaN outside the hull; needs >= 2 knots */
+};
+
+/* return codes */
+enum {
+    IVS_OK            = 0,
+    IVS_EINVAL        = -22, /* bad argument (null pointer, negative size, unknown method) */
+    IVS_ERANGE        = -34, /* shape outside what the kernels support (see ivs_last_error) */
+    IVS_ENOMEM        = -12, /* workspace too small */
+    IVS_ELAUNCH       = -5   /* HIP launch error */
+};
+
+/* per-item status bits written to `status` arrays */
+enum {
+    IVS_ST_OK            = 0,
+    IVS_ST_TOO_FEW_KNOTS = 1  /* the reference's scipy call raises here -> interpolate_symbol returns None */
+};
+
+int         ivs_version(void);        /* IVS_ABI_VERSION of the loaded library */
+const char* ivs_last_error(void);     /* host pointer, valid until the next call on this thread */
+int         ivs_device_count(void);   /* number of visible HIP devices (0 if none) */
+
+/*
+ * Batch of 1-D series, C channels sharing knot coordinates: the arithmetic of
+ * core.py:58-61 (three channels of one symbol) for S symbols at once.
+ *
+ *   xk  [total_knots]            knot coordinates of all series back to back, ascending within a series
+ *   yk  [C][yk_stride]           channel c of knot i at yk[c*yk_stride + i]; NaN = not a knot for that channel
+ *   knot_off [S+1]               CSR offsets into xk / yk
+ *   xq  [total_queries] or NULL  query coordinates; NULL = 0,1,..,m_s-1 per series (the reference's RangeIndex)
+ *   q_off [S+1]                  CSR offsets into xq / out
+ *   out [C][out_stride]          result of channel c, query i at out[c*out_stride + i]
+ *   status [S*C]                 IVS_ST_* per (series, channel)
+ *   workspace                    ivs_interp1d_workspace_bytes(total_knots, S, C) bytes of device memory
+ */
+size_t ivs_interp1d_workspace_bytes(int64_t total_knots, int64_t n_series, int32_t n_channels);
+int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
+                           int64_t n_series, int32_t n_channels, int64_t total_knots,
+                           const double* xq, const int64_t* q_off, int64_t total_queries,
+                           double* out, int64_t out_stride, int32_t* status, int32_t method,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Forward-fill gather index: the "index of the last valid source row at or before
+ * output row i" of core.py:64-68 (nine `fillna(method='ffill')` columns), for S symbols.
+ *
+ *   src_pos [total_src]          merged-frame row position of every source row, ascending within a series
+ *   src_off [S+1]                CSR offsets into src_pos / valid
+ *   valid   [n_cols][valid_stride]  1 = source cell is non-null in that column
+ *   q_off   [S+1]                CSR offsets of the output rows (row i of series s is position i - q_off[s])
+ *   idx_out [n_cols][out_stride] flat source-row index to gather from, or -1 (stays null)
+ */
+int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const uint8_t* valid, int64_t valid_stride,
+                          int32_t n_cols, const int64_t* q_off, int64_t n_series, int64_t total_queries,
+                          int32_t* idx_out, int64_t out_stride, void* stream);
+
+/*
+ * Batch of (strike x maturity) surfaces: strike pass then maturity pass, each pass the
+ * 1-D operator above (this repository's documented composition).
+ *
+ *   K      strikes.  k_off == NULL: surface b at K + b*k_stride (k_stride 0 = one shared grid), nK each.
+ *                    k_off != NULL: ragged, surface b has k_off[b+1]-k_off[b] strikes at K + k_off[b];
+ *                                   nK is then the maximum count in the batch.
+ *   T      maturities of surface b at T + b*t_stride (0 = shared), nT each (nT <= 32)
+ *   sigma  surface b at sigma + nT*nK*b (uniform) or sigma + nT*k_off[b] (ragged); [nT][nK_b] row-major
+ *   Kq/Tq  query grids of surface b at Kq + b*kq_stride / Tq + b*tq_stride (0 = shared), mK / mT points
+ *   out    [B][mT][mK]
+ *   status [B] or NULL; IVS_ST_* OR-ed over every 1-D solve of the surface
+ *   flags  0, or IVS_FLAG_FORCE_GENERIC to bypass the dense fast path (testing / A-B timing)
+ */
+enum { IVS_FLAG_FORCE_GENERIC = 1 };
+int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_stride, int32_t nK,
+                          const double* T, int64_t t_stride, int32_t nT,
+                          const double* sigma, int64_t B,
+                          const double* Kq, int64_t kq_stride, int32_t mK,
+                          const double* Tq, int64_t tq_stride, int32_t mT,
+                          double* out, int32_t* status, int32_t method, int32_t flags, void* stream);
+
+/* name of the kernel the last ivs_surface_batch_f64 call on this thread dispatched to (host string) */
+const char* ivs_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVS_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libivs.so (the C ABI in include/ivs.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C iv_interpolation_amd/csrc``.
+There is NO CPU fallback: if the shared object is missing or no HIP device is visible the
+product path raises ``EngineUnavailable``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libivs.so")
+
+LINEAR, CUBIC, CUBICSPLINE, SLINEAR = 0, 1, 2, 3
+ST_OK, ST_TOO_FEW_KNOTS = 0, 1
+FLAG_FORCE_GENERIC = 1
+ABI_VERSION = 1
+
+# pandas method names (reference core.py:61 forwards self.method) -> engine codes
+METHOD_CODES = {"linear": LINEAR, "index": LINEAR, "values": LINEAR,
+                "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR}
+
+
+class EngineUnavailable(RuntimeError):
+    """libivs.so missing / not loadable / no MI355X visible.  Never swallowed by the host code."""
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call returned a negative code."""
+
+
+_p = C.c_void_p
+_i64, _i32, _sz = C.c_int64, C.c_int32, C.c_size_t
+
+# every symbol include/ivs.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "ivs_version": (C.c_int, []),
+    "ivs_last_error": (C.c_char_p, []),
+    "ivs_last_kernel": (C.c_char_p, []),
+    "ivs_device_count": (C.c_int, []),
+    "ivs_interp1d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "ivs_interp1d_batch_f64": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _i64, _p, _p, _i64, _p, _i64, _p, _i32,
+                                         _p, _sz, _p]),
+    "ivs_ffill_index_batch": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _i64, _p, _i64, _p]),
+    "ivs_surface_batch_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i32,
+                                        _p, _p, _i32, _i32, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libivs.so (no GPU needed for loading).  Raises EngineUnavailable if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise EngineUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EngineUnavailable(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ivs_version() != ABI_VERSION:
+        raise EngineUnavailable(f"libivs.so ABI {lib.ivs_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise EngineError(f"{what} failed ({rc}): {load().ivs_last_error().decode()}")

@@ -1,0 +1,240 @@
+"""Drop-in replacement for the reference's ``src/interpolation/core.py``.
+
+Same class, same constructor, same ``interpolate_symbol(df) -> Optional[DataFrame]`` contract
+(reference core.py:9-85; callers: complete_pipeline.py:318, batch_processor.py:97,
+optimized_batch_processor.py:303,349), but the arithmetic -- the three interpolated channels
+(core.py:58-61) and the forward-fill gather index (core.py:64-68) -- runs in HIP kernels on an
+MI355X through the C ABI in include/ivs.h.  ``interpolate_batch`` is the columnar many-symbols
+extension: every symbol of the batch goes to the device in ONE launch
+per kernel instead of one DataFrame round trip per symbol.
+
+Host code does what the reference's pandas calls do around the numbers (rules R1-R14 of
+SURVEY.md section 8a): guards, sort, minute lattice, exact-timestamp join with duplicate expansion,
+column order / dtypes / index of the result.  There is no CPU fallback for the numerics:
+a missing libivs.so or GPU raises ``EngineUnavailable`` (it is NOT turned into ``None``).
+"""
+from __future__ import annotations
+
+import logging
+from datetime import timedelta
+from typing import List, Optional, Sequence
+
+import numpy as np
+import pandas as pd
+
+from ._lib import METHOD_CODES, ST_OK, EngineUnavailable
+
+logger = logging.getLogger("interpolation.core")   # the reference's logger name (core.py:7)
+
+NUMERIC_COLS = ["iv", "underlying_price", "time_to_maturity"]                      # core.py:58
+FILL_COLS = ["symbol", "strike", "callput", "interest_rate", "mark_price",         # core.py:64-65
+             "index_price", "volume", "quote_volume", "record_time"]
+REQUIRED = ["symbol", "iv", "underlying_price", "time_to_maturity"]                 # core.py:74
+MINUTE_NS = 60_000_000_000
+
+# pandas accepts these names; the ones not in METHOD_CODES are not implemented by the engine yet
+_PANDAS_METHODS = ["linear", "time", "index", "values", "nearest", "zero", "slinear", "quadratic", "cubic",
+                   "barycentric", "krogh", "spline", "polynomial", "from_derivatives", "piecewise_polynomial",
+                   "pchip", "akima", "cubicspline"]
+
+
+class HipBackend:
+    """Moves packed host columns to the current HIP device and calls the kernels."""
+
+    def interp1d_batch(self, xk, yk, knot_off, q_off, total_q, code):
+        from . import engine
+        torch = engine.require_device()
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        out, st = engine.interp1d_batch(d(xk), d(yk), d(knot_off), d(q_off), int(total_q), code)
+        return out.cpu().numpy(), st.cpu().numpy()
+
+    def ffill_index_batch(self, src_pos, src_off, valid, q_off, total_q):
+        from . import engine
+        torch = engine.require_device()
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        return engine.ffill_index_batch(d(src_pos), d(src_off), d(valid), d(q_off), int(total_q)).cpu().numpy()
+
+
+class _Prepared:
+    __slots__ = ("df", "timeline", "rows_on", "pos", "rowlat", "M", "chan_src", "chan_needs", "fill_cols",
+                 "fill_valid", "other_cols")
+
+
+class IVInterpolator:
+    """Core interpolation engine for IV data (MI355X-native)."""
+
+    def __init__(self, method: str = "linear", min_points: int = 10, backend=None):
+        self.method = method
+        self.min_points = min_points
+        self._backend = backend          # None -> HipBackend on first use
+
+    # ------------------------------------------------------------------ public API
+    def interpolate_symbol(self, symbol_data: pd.DataFrame) -> Optional[pd.DataFrame]:
+        """Interpolate IV data for a single symbol (hourly rows -> 1-minute rows) or None."""
+        return self.interpolate_batch([symbol_data])[0]
+
+    def interpolate_batch(self, frames: Sequence[pd.DataFrame]) -> List[Optional[pd.DataFrame]]:
+        """Many symbols, one device round trip.  Element i is what interpolate_symbol(frames[i]) returns."""
+        preps: List[Optional[_Prepared]] = []
+        for f in frames:
+            try:
+                preps.append(self._prepare(f))
+            except EngineUnavailable:
+                raise
+            except Exception as e:                                       # core.py:83-85
+                logger.error(f"Interpolation failed: {e}")
+                preps.append(None)
+        live = [i for i, p in enumerate(preps) if p is not None]
+        results: List[Optional[pd.DataFrame]] = [None] * len(frames)
+        if not live:
+            return results
+        be = self._backend or HipBackend()
+        code = METHOD_CODES[self.method]
+        # ---- pack (CSR over symbols)
+        ps = [preps[i] for i in live]
+        n_src = np.array([len(p.pos) for p in ps], np.int64)
+        n_out = np.array([p.M for p in ps], np.int64)
+        src_off = np.concatenate([[0], np.cumsum(n_src)]).astype(np.int64)
+        q_off = np.concatenate([[0], np.cumsum(n_out)]).astype(np.int64)
+        total_q = int(q_off[-1])
+        xk = np.concatenate([p.pos for p in ps]).astype(np.float64)
+        yk = np.stack([np.concatenate([p.chan_src[c] for p in ps]) for c in range(len(NUMERIC_COLS))])
+        out, status = be.interp1d_batch(xk, yk, src_off, q_off, total_q, code)
+        ncols = max((len(p.fill_cols) for p in ps), default=0)
+        idx = None
+        if ncols:
+            valid = np.zeros((ncols, int(src_off[-1])), np.uint8)
+            for k, p in enumerate(ps):
+                for c in range(len(p.fill_cols)):
+                    valid[c, src_off[k]:src_off[k + 1]] = p.fill_valid[c]
+            src_pos = np.concatenate([p.pos for p in ps]).astype(np.int64)
+            idx = be.ffill_index_batch(src_pos, src_off, valid, q_off, total_q)
+        # ---- unpack
+        for k, i in enumerate(live):
+            p = ps[k]
+            try:
+                results[i] = self._assemble(p, out[:, q_off[k]:q_off[k + 1]], status[k],
+                                            None if idx is None else idx[:, q_off[k]:q_off[k + 1]] - src_off[k],
+                                            None if idx is None else idx[:, q_off[k]:q_off[k + 1]] < 0)
+            except EngineUnavailable:
+                raise
+            except Exception as e:                                       # core.py:83-85
+                logger.error(f"Interpolation failed: {e}")
+                results[i] = None
+        return results
+
+    # ------------------------------------------------------------------ host bookkeeping
+    def _prepare(self, symbol_data: pd.DataFrame) -> Optional[_Prepared]:
+        if len(symbol_data) < self.min_points:                           # core.py:26-28
+            logger.warning(f"Insufficient data points: {len(symbol_data)} < {self.min_points}")
+            return None
+        df = symbol_data.sort_values("date").reset_index(drop=True)     # core.py:32 (same pandas call, same order)
+        df["date"] = pd.to_datetime(df["date"])                          # core.py:33
+        dmin, dmax = df["date"].min(), df["date"].max()
+        time_range = dmax - dmin
+        if time_range > timedelta(days=30):                              # core.py:36-39
+            logger.warning(f"Time range too large: {time_range}")
+            return None
+        timeline = pd.date_range(start=dmin, end=dmax, freq="1min")      # core.py:42-46
+        if len(timeline) > 100000:                                       # core.py:49-51
+            logger.warning(f"Timeline too long: {len(timeline)} minutes")
+            return None
+        if self.method not in METHOD_CODES:
+            if self.method not in _PANDAS_METHODS:
+                raise ValueError(f"method must be one of {_PANDAS_METHODS}. Got '{self.method}' instead.")
+            if self.method == "time":
+                raise ValueError("time-weighted interpolation only works on Series or DataFrames with a DatetimeIndex")
+            if self.method in ("spline", "polynomial"):
+                raise ValueError("You must specify the order of the spline or polynomial.")
+            raise ValueError(f"method '{self.method}' is valid for pandas but not implemented by the MI355X engine "
+                             f"(implemented: {sorted(METHOD_CODES)})")
+        for c in REQUIRED:                                               # dropna(subset=...) KeyError, core.py:74
+            if c not in df.columns:
+                raise KeyError(c)
+        # exact-timestamp left join (core.py:54-55) as integer lattice arithmetic
+        t_ns = pd.DatetimeIndex(timeline).as_unit("ns").asi8
+        d_idx = pd.DatetimeIndex(df["date"]).as_unit("ns")
+        d_ns = d_idx.asi8
+        rel = d_ns - t_ns[0]
+        on = (~np.asarray(d_idx.isna())) & (rel >= 0) & (rel % MINUTE_NS == 0)
+        rows_on = np.flatnonzero(on)                                     # off-lattice rows vanish (R6)
+        lat = rel[rows_on] // MINUTE_NS
+        q = len(rows_on)
+        first = np.ones(q, bool); first[1:] = lat[1:] != lat[:-1]
+        u = np.cumsum(first)
+        pos = lat + np.arange(q) + 1 - u                                 # duplicates take consecutive rows (R7, R8)
+        m0 = len(timeline)
+        M = m0 + (q - int(u[-1]))
+        if M == m0:
+            rowlat = None
+        else:
+            cnt = np.maximum(np.bincount(lat, minlength=m0), 1)
+            rowlat = np.repeat(np.arange(m0), cnt)
+        p = _Prepared()
+        p.df, p.timeline, p.rows_on, p.pos, p.rowlat, p.M = df, timeline, rows_on, pos, rowlat, M
+        p.chan_src, p.chan_needs = [], []
+        for c in NUMERIC_COLS:                                           # core.py:58-61
+            v = df[c].to_numpy(dtype=np.float64, na_value=np.nan)[rows_on]
+            p.chan_src.append(v)
+            nn = int(np.isnan(v).sum()) + (M - q)                        # NaNs of the merged column
+            p.chan_needs.append(0 < nn < M)                              # pandas: all-NaN / no-NaN columns are left alone
+        p.fill_cols = [c for c in FILL_COLS if c in df.columns]          # core.py:64-68
+        p.fill_valid = [df[c].notna().to_numpy()[rows_on].astype(np.uint8) for c in p.fill_cols]
+        p.other_cols = [c for c in df.columns if c != "date" and c not in NUMERIC_COLS and c not in FILL_COLS]
+        return p
+
+    def _assemble(self, p: _Prepared, out, status, fill_idx, fill_missing) -> Optional[pd.DataFrame]:
+        df, M = p.df, p.M
+        for c in range(len(NUMERIC_COLS)):
+            if p.chan_needs[c] and status[c] != ST_OK:
+                # scipy raises inside Series.interpolate (too few knots) -> core.py:83-85
+                raise ValueError("The number of derivatives at boundaries does not match: "
+                                 f"too few valid knots in '{NUMERIC_COLS[c]}' for method '{self.method}'")
+        src = df.iloc[p.rows_on].reset_index(drop=True)
+        raw_idx = np.full(M, -1, np.int64)
+        raw_idx[p.pos] = np.arange(len(p.pos))
+        cols = {}
+        dates = p.timeline if p.rowlat is None else p.timeline[p.rowlat]
+        cols["date"] = pd.Series(dates).reset_index(drop=True)
+        for name in df.columns:
+            if name == "date":
+                continue
+            if name in NUMERIC_COLS:
+                ci = NUMERIC_COLS.index(name)
+                merged = np.full(M, np.nan)
+                merged[p.pos] = p.chan_src[ci]
+                if p.chan_needs[ci]:
+                    merged = np.where(np.isnan(merged), out[ci], merged)
+                s = pd.Series(merged)
+                if M == len(p.pos) and df[name].dtype.kind in "iu":      # nothing missing: int column stays int
+                    s = s.astype(df[name].dtype)
+                cols[name] = s
+            elif name in p.fill_cols:
+                fi = p.fill_cols.index(name)
+                gi = np.where(fill_missing[fi], -1, fill_idx[fi])
+                cols[name] = _gather(src[name], gi, M == len(p.pos))
+            else:
+                cols[name] = _gather(src[name], raw_idx, M == len(p.pos))
+        merged = pd.DataFrame(cols, columns=["date"] + [c for c in df.columns if c != "date"])
+        merged["is_interpolated"] = merged["symbol"].isna().to_numpy()   # core.py:71 (after ffill -> always False)
+        keep = np.ones(M, bool)
+        for c in REQUIRED:                                               # core.py:74
+            keep &= merged[c].notna().to_numpy()
+        if not keep.all():
+            merged = merged[keep]
+        if merged.empty:                                                 # core.py:76-78
+            logger.warning("No valid data after interpolation")
+            return None
+        logger.debug(f"Interpolated {len(df)} → {len(merged)} rows")
+        return merged
+
+
+def _gather(col: pd.Series, idx: np.ndarray, nothing_missing: bool) -> pd.Series:
+    """col[idx] with -1 -> missing, dtype-promoting exactly like a left merge (int -> float, object -> NaN)."""
+    if nothing_missing and (idx >= 0).all():
+        return col.take(idx).reset_index(drop=True)
+    if (idx >= 0).all() and col.dtype.kind in "iub":
+        # the merge introduced missing rows elsewhere in the frame -> pandas already promoted this column
+        return col.astype(np.float64).take(idx).reset_index(drop=True)
+    r = col.reindex(idx)          # label -1 is absent from the RangeIndex -> NaN / None / NaT
+    return r.reset_index(drop=True)

@@ -1,0 +1,180 @@
+// extern "C" entry points of libivs.so (declared in include/ivs.h).
+// Argument validation happens here on the host; kernels assume validated shapes.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ivs.h"
+#include "ivs_interp1d.hpp"
+#include "ivs_surface_dense.hpp"
+#include "ivs_surface_generic.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local const char* g_last_kernel = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(IVS_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return IVS_OK;
+}
+
+bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_SLINEAR; }
+
+int g_num_cu = 0;
+int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivs_version(void) { return IVS_ABI_VERSION; }
+
+const char* ivs_last_error(void) { return g_err; }
+
+const char* ivs_last_kernel(void) { return g_last_kernel; }
+
+int ivs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+size_t ivs_interp1d_workspace_bytes(int64_t total_knots, int64_t n_series, int32_t n_channels) {
+    if (total_knots < 0 || n_series < 0 || n_channels < 0) return 0;
+    return ivs::interp1d_ws_bytes(total_knots, n_series, n_channels);
+}
+
+int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
+                           int64_t n_series, int32_t n_channels, int64_t total_knots,
+                           const double* xq, const int64_t* q_off, int64_t total_queries,
+                           double* out, int64_t out_stride, int32_t* status, int32_t method,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    if (!valid_method(method)) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: unknown method %d", method);
+    if (n_series < 0 || n_channels < 0 || total_knots < 0 || total_queries < 0)
+        return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: negative size");
+    if (n_series == 0 || n_channels == 0) return IVS_OK;
+    if (!knot_off || !q_off || !status) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: null offsets/status");
+    if (total_knots > 0 && (!xk || !yk)) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: null knots");
+    if (total_queries > 0 && !out) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: null out");
+    if (yk_stride < total_knots || out_stride < total_queries)
+        return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: channel stride smaller than row length");
+    if (n_series * (int64_t)n_channels > 0x7fffffffLL || (total_queries + 255) / 256 > 0x7fffffffLL)
+        return fail(IVS_ERANGE, "ivs_interp1d_batch_f64: batch too large for one launch");
+    size_t need = ivs::interp1d_ws_bytes(total_knots, n_series, n_channels);
+    if (!workspace || workspace_bytes < need)
+        return fail(IVS_ENOMEM, "ivs_interp1d_batch_f64: workspace %zu < %zu bytes", workspace_bytes, need);
+
+    ivs::Interp1dParams p;
+    p.xk = xk; p.yk = yk; p.yk_stride = yk_stride; p.knot_off = knot_off;
+    p.S = n_series; p.C = n_channels; p.total_knots = total_knots;
+    p.xq = xq; p.q_off = q_off; p.total_q = total_queries;
+    p.out = out; p.out_stride = out_stride; p.status = status; p.method = method;
+    double* w = static_cast<double*>(workspace);
+    size_t plane = (size_t)n_channels * (size_t)total_knots;
+    p.wx = w; p.wy = w + plane; p.ws = w + 2 * plane; p.wcp = w + 3 * plane;
+    p.wn = reinterpret_cast<int32_t*>(w + 4 * plane);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ivs::interp1d_prepare_kernel, dim3((unsigned)(n_series * n_channels)), dim3(256), 0, st, p);
+    int rc = check_launch("interp1d_prepare_kernel");
+    if (rc) return rc;
+    if (total_queries > 0) {
+        hipLaunchKernelGGL(ivs::interp1d_eval_kernel, dim3((unsigned)((total_queries + 255) / 256)), dim3(256), 0, st, p);
+        rc = check_launch("interp1d_eval_kernel");
+    }
+    return rc;
+}
+
+int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const uint8_t* valid, int64_t valid_stride,
+                          int32_t n_cols, const int64_t* q_off, int64_t n_series, int64_t total_queries,
+                          int32_t* idx_out, int64_t out_stride, void* stream) {
+    g_err[0] = 0;
+    if (n_cols < 0 || n_series < 0 || total_queries < 0) return fail(IVS_EINVAL, "ivs_ffill_index_batch: negative size");
+    if (n_cols == 0 || n_series == 0 || total_queries == 0) return IVS_OK;
+    if (!src_pos || !src_off || !valid || !q_off || !idx_out) return fail(IVS_EINVAL, "ivs_ffill_index_batch: null pointer");
+    if (out_stride < total_queries) return fail(IVS_EINVAL, "ivs_ffill_index_batch: out_stride < total_queries");
+    if ((total_queries + 255) / 256 > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_ffill_index_batch: too many rows");
+    ivs::FfillParams p{src_pos, src_off, valid, valid_stride, n_cols, q_off, n_series, total_queries, idx_out, out_stride};
+    hipLaunchKernelGGL(ivs::ffill_index_kernel, dim3((unsigned)((total_queries + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    return check_launch("ffill_index_kernel");
+}
+
+int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_stride, int32_t nK,
+                          const double* T, int64_t t_stride, int32_t nT,
+                          const double* sigma, int64_t B,
+                          const double* Kq, int64_t kq_stride, int32_t mK,
+                          const double* Tq, int64_t tq_stride, int32_t mT,
+                          double* out, int32_t* status, int32_t method, int32_t flags, void* stream) {
+    g_err[0] = 0;
+    g_last_kernel = "";
+    if (!valid_method(method)) return fail(IVS_EINVAL, "ivs_surface_batch_f64: unknown method %d", method);
+    if (B < 0 || nK < 0 || nT < 0 || mK < 0 || mT < 0) return fail(IVS_EINVAL, "ivs_surface_batch_f64: negative size");
+    if (B == 0 || mK == 0 || mT == 0) return IVS_OK;
+    if (!K || !T || !sigma || !Kq || !Tq || !out) return fail(IVS_EINVAL, "ivs_surface_batch_f64: null pointer");
+    if (nT < 1 || nT > ivs::GEN_NTMAX) return fail(IVS_ERANGE, "ivs_surface_batch_f64: nT=%d outside [1,%d]", nT, ivs::GEN_NTMAX);
+    if (nK < 1) return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d < 1", nK);
+    if (!k_off && k_stride != 0 && k_stride < nK) return fail(IVS_EINVAL, "ivs_surface_batch_f64: k_stride < nK");
+    if (t_stride < 0 || kq_stride < 0 || tq_stride < 0 || k_stride < 0)
+        return fail(IVS_EINVAL, "ivs_surface_batch_f64: negative stride");
+
+    ivs::SurfaceParams p;
+    p.K = K; p.k_off = k_off; p.k_stride = k_stride; p.nK = nK;
+    p.T = T; p.t_stride = t_stride; p.nT = nT;
+    p.sigma = sigma; p.B = B;
+    p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;
+    p.Tq = Tq; p.tq_stride = tq_stride; p.mT = mT;
+    p.out = out; p.status = status; p.method = method;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    if (!(flags & IVS_FLAG_FORCE_GENERIC)) {
+        const char* name = nullptr;
+        int rc = ivs::launch_surface_dense(p, num_cu(), st, &name);
+        if (rc == 1) {   // dispatched
+            g_last_kernel = name;
+            return check_launch(name);
+        }
+        if (rc < 0) return fail(IVS_ELAUNCH, "ivs_surface_batch_f64: dense dispatch failed");
+    }
+
+    size_t lds = ivs::generic_lds_bytes(nK, nT);
+    if (lds > 160 * 1024)
+        return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d x nT=%d needs %zu B of LDS (> 160 KiB)", nK, nT, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ivs::surface_generic_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 16) per_cu = 16;
+    int64_t grid = (int64_t)num_cu() * per_cu * 2;
+    if (grid > B) grid = B;
+    g_last_kernel = "surface_generic_kernel";
+    hipLaunchKernelGGL(ivs::surface_generic_kernel, dim3((unsigned)grid), dim3(64), lds, st, p);
+    return check_launch("surface_generic_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// Generic surface kernel: any strike count (ragged CSR), NaN-masked quotes, all four methods.
+//
+// One 64-lane workgroup (= one wavefront) per surface, grid-stride over the batch.
+//   1. quotes of row t are loaded coalesced (lane = strike) and compacted with a wave ballot
+//      into LDS (xs/ys[t][rank]); rows keep their own knot sets (NaN = missing quote).
+//   2. cubic methods: lane t runs the not-a-knot Thomas recurrence of row t in LDS.
+//   3. per block of 64 query strikes (lane = query): evaluate every row at the lane's strike,
+//      compacting non-NaN results into a lane-private LDS column; solve the column's own
+//      not-a-knot system; evaluate at every query maturity and store out[tq][q] coalesced.
+// This is the correctness-first path; the dense fast path lives in ivs_surface_dense.hpp.
+#pragma once
+#include "ivs_device.hpp"
+
+namespace ivs {
+
+struct SurfaceParams {
+    const double* K; const int64_t* k_off; int64_t k_stride; int nK;
+    const double* T; int64_t t_stride; int nT;
+    const double* sigma; int64_t B;
+    const double* Kq; int64_t kq_stride; int mK;
+    const double* Tq; int64_t tq_stride; int mT;
+    double* out; int32_t* status; int method;
+};
+
+constexpr int GEN_NTMAX = 32;
+
+// LDS carve (per workgroup) in doubles; LK = nKmax + 1 (row pad)
+__host__ __device__ inline size_t generic_lds_bytes(int nKmax, int nT) {
+    size_t LK = (size_t)nKmax + 1;
+    size_t rows = (size_t)nT * LK;
+    size_t scratch = rows > (size_t)nT * 64 ? rows : (size_t)nT * 64;   // row cp[] aliases column cp[]
+    size_t doubles = (size_t)nKmax + GEN_NTMAX      // Ksh, Tsh
+                     + 3 * rows                      // xs, ys, ss
+                     + scratch                       // cps / ccp
+                     + 2 * (size_t)nT * 64;          // cz, cs
+    return doubles * 8 + (size_t)nT * 64 /*ctidx*/ + GEN_NTMAX * 4 /*nrow*/;
+}
+
+struct ColX {   // column knot coordinate = Tsh[ctidx[r][lane]]
+    const uint8_t* idx; const double* T;
+    __device__ __forceinline__ double operator()(int i) const { return T[idx[i * 64]]; }
+};
+
+__global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int nT = p.nT, nKmax = p.nK, LK = nKmax + 1;
+    const int method = p.method;
+    const bool cubic = method_is_cubic(method);
+    const bool hold = method == IVS_LINEAR;
+    const bool extrap = method == IVS_CUBICSPLINE;
+    const int minkn = method_min_knots(method);
+
+    double* Ksh = reinterpret_cast<double*>(smem);
+    double* Tsh = Ksh + nKmax;
+    double* xs = Tsh + GEN_NTMAX;
+    double* ys = xs + (size_t)nT * LK;
+    double* ss = ys + (size_t)nT * LK;
+    double* cps = ss + (size_t)nT * LK;
+    size_t scratch = (size_t)nT * LK > (size_t)nT * 64 ? (size_t)nT * LK : (size_t)nT * 64;
+    double* cz = cps + scratch;
+    double* cs = cz + (size_t)nT * 64;
+    uint8_t* ctidx = reinterpret_cast<uint8_t*>(cs + (size_t)nT * 64);
+    int* nrow = reinterpret_cast<int*>(ctidx + (size_t)nT * 64);
+
+    for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
+        int64_t koff; int nKb;
+        if (p.k_off) { koff = p.k_off[b]; nKb = (int)(p.k_off[b + 1] - koff); }
+        else { koff = b * p.k_stride; nKb = nKmax; }
+        const double* Kb = p.K + koff;
+        const double* sb = p.k_off ? p.sigma + (int64_t)nT * koff : p.sigma + b * (int64_t)nT * nKmax;
+        const double* Tb = p.T + b * p.t_stride;
+        const double* Kqb = p.Kq + b * p.kq_stride;
+        const double* Tqb = p.Tq + b * p.tq_stride;
+        double* outb = p.out + b * (int64_t)p.mT * p.mK;
+        int st = 0;
+
+        __syncthreads();   // previous surface's readers are done with LDS
+        for (int k = lane; k < nKb; k += 64) Ksh[k] = Kb[k];
+        if (lane < nT) Tsh[lane] = Tb[lane];
+        // 1. load + compact rows
+        for (int t = 0; t < nT; ++t) {
+            int cnt = 0;
+            for (int c0 = 0; c0 < nKb; c0 += 64) {
+                int k = c0 + lane;
+                double v = k < nKb ? sb[(int64_t)t * nKb + k] : qnan();
+                bool valid = !__builtin_isnan(v);
+                unsigned long long m = __ballot(valid);
+                int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (valid) { xs[t * LK + rank] = Kb[k]; ys[t * LK + rank] = v; }
+                cnt += __popcll(m);
+            }
+            if (lane == 0) nrow[t] = cnt;
+        }
+        __syncthreads();
+        // 2. strike-direction slopes, lane = row
+        if (cubic && lane < nT) {
+            int n = nrow[lane];
+            if (n >= minkn && n >= 2) {
+                CView x{xs + lane * LK, 1}, y{ys + lane * LK, 1};
+                View s{ss + lane * LK, 1}, c{cps + lane * LK, 1};
+                nak_slopes(x, y, s, c, n);
+            }
+        }
+        __syncthreads();
+        // 3. per query block
+        for (int q0 = 0; q0 < p.mK; q0 += 64) {
+            int q = q0 + lane;
+            bool active = q < p.mK;
+            double xq = active ? Kqb[q] : qnan();
+            CView kfull{Ksh, 1};
+            int jfull = find_interval(kfull, nKb, xq);
+            int cn = 0;   // valid knots in this lane's column
+            for (int t = 0; t < nT; ++t) {
+                int n = nrow[t];
+                double z = qnan();
+                if (n > 0 && n < minkn) {
+                    st |= IVS_ST_TOO_FEW_KNOTS;
+                } else if (n > 0) {
+                    CView x{xs + t * LK, 1}, y{ys + t * LK, 1}, s{ss + t * LK, 1};
+                    int j = (n == nKb) ? jfull : find_interval(x, n, xq);
+                    z = cubic ? eval_cubic(x, y, s, n, j, xq, extrap) : eval_linear(x, y, n, j, xq, hold);
+                }
+                if (!__builtin_isnan(z)) {
+                    cz[cn * 64 + lane] = z;
+                    ctidx[cn * 64 + lane] = (uint8_t)t;
+                    ++cn;
+                }
+            }
+            // maturity direction, lane-private column
+            ColX cx{ctidx + lane, Tsh};
+            CView cy{cz + lane, 64};
+            View csv{cs + lane, 64}, ccp{cps + lane, 64};
+            bool few = cn > 0 && cn < minkn;
+            if (few && active) st |= IVS_ST_TOO_FEW_KNOTS;
+            bool solvable = cn > 0 && !few;
+            if (cubic && solvable && cn >= 2) nak_slopes(cx, cy, csv, ccp, cn);
+            for (int tq = 0; tq < p.mT; ++tq) {
+                double r = qnan();
+                if (solvable) {
+                    double x = Tqb[tq];
+                    int j = find_interval(cx, cn, x);
+                    CView csr{cs + lane, 64};
+                    r = cubic ? eval_cubic(cx, cy, csr, cn, j, x, extrap) : eval_linear(cx, cy, cn, j, x, hold);
+                }
+                if (active) outb[(int64_t)tq * p.mK + q] = r;
+            }
+        }
+        if (p.status) {
+            // OR over lanes
+            unsigned long long any = __ballot(st != 0);
+            if (lane == 0) p.status[b] = any ? IVS_ST_TOO_FEW_KNOTS : IVS_ST_OK;
+        }
+    }
+}
+
+}  // namespace ivs

@@ -1,0 +1,119 @@
+"""Thin device-side wrappers: torch-ROCm tensors are only device buffers and streams here;
+all arithmetic happens in the HIP kernels behind the C ABI (include/ivs.h)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+from . import _lib
+from ._lib import EngineUnavailable
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_device():
+    """Return torch, after checking that the HIP library loads and a GPU is visible."""
+    lib = _lib.load()
+    torch = _torch()
+    if not torch.cuda.is_available() or lib.ivs_device_count() < 1:
+        raise EngineUnavailable("no MI355X / HIP device visible: the interpolation engine has no CPU fallback")
+    return torch
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(torch, stream):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return s.cuda_stream
+
+
+def _f64(torch, t, name):
+    if t.dtype != torch.float64 or not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA float64 tensor")
+    return t.contiguous()
+
+
+def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: Optional[int] = None,
+                  n_maturities: Optional[int] = None, out=None, status=None, stream=None,
+                  force_generic: bool = False):
+    """Interpolate a batch of (strike x maturity) surfaces on the current device.
+
+    Uniform: K [B,nK] or [nK] (shared), sigma [B,nT,nK].  Ragged: K flat [total], sigma flat
+    [nT*total] (surface b row-major [nT][nK_b]), k_off int64 [B+1], nK_max, n_maturities.
+    T [nT] or [B,nT]; Kq [mK] or [B,mK]; Tq [mT] or [B,mT].  Returns (out [B,mT,mK], status [B]).
+    """
+    torch = require_device()
+    lib = _lib.load()
+    code = _lib.METHOD_CODES[method] if isinstance(method, str) else int(method)
+    K = _f64(torch, K, "K"); T = _f64(torch, T, "T"); sigma = _f64(torch, sigma, "sigma")
+    Kq = _f64(torch, Kq, "Kq"); Tq = _f64(torch, Tq, "Tq")
+    if k_off is None:
+        B, nT, nK = sigma.shape
+        k_stride = 0 if K.dim() == 1 else nK
+        if K.shape[-1] != nK or (K.dim() == 2 and K.shape[0] != B):
+            raise ValueError("K shape does not match sigma")
+    else:
+        if k_off.dtype != torch.int64 or not k_off.is_cuda:
+            raise TypeError("k_off must be a CUDA int64 tensor")
+        if nK_max is None or n_maturities is None:
+            raise ValueError("ragged batches need nK_max and n_maturities")
+        B = k_off.numel() - 1; nT = int(n_maturities); nK = int(nK_max); k_stride = 0
+    if T.shape[-1] != nT or (T.dim() == 2 and T.shape[0] != B):
+        raise ValueError("T shape does not match sigma")
+    t_stride = 0 if T.dim() == 1 else nT
+    mK, mT = Kq.shape[-1], Tq.shape[-1]
+    if (Kq.dim() == 2 and Kq.shape[0] != B) or (Tq.dim() == 2 and Tq.shape[0] != B):
+        raise ValueError("per-surface query grids must have B rows")
+    kq_stride = 0 if Kq.dim() == 1 else mK
+    tq_stride = 0 if Tq.dim() == 1 else mT
+    if out is None:
+        out = torch.empty((B, mT, mK), dtype=torch.float64, device=sigma.device)
+    if status is None:
+        status = torch.empty((B,), dtype=torch.int32, device=sigma.device)
+    rc = lib.ivs_surface_batch_f64(_ptr(K), _ptr(k_off), k_stride, nK, _ptr(T), t_stride, nT, _ptr(sigma), B,
+                                   _ptr(Kq), kq_stride, mK, _ptr(Tq), tq_stride, mT, _ptr(out), _ptr(status),
+                                   code, _lib.FLAG_FORCE_GENERIC if force_generic else 0, _stream(torch, stream))
+    _lib.check(rc, "ivs_surface_batch_f64")
+    return out, status
+
+
+def last_kernel() -> str:
+    return _lib.load().ivs_last_kernel().decode()
+
+
+def interp1d_batch(xk, yk, knot_off, q_off, total_q: int, method, xq=None, stream=None) -> Tuple[object, object]:
+    """CSR batch of 1-D series.  xk [TK], yk [C,TK], knot_off/q_off int64 [S+1] (device).
+    Returns (out [C,total_q], status [S,C])."""
+    torch = require_device()
+    lib = _lib.load()
+    code = _lib.METHOD_CODES[method] if isinstance(method, str) else int(method)
+    xk = _f64(torch, xk, "xk"); yk = _f64(torch, yk, "yk")
+    Cn, TK = yk.shape
+    S = knot_off.numel() - 1
+    dev = yk.device
+    out = torch.empty((Cn, total_q), dtype=torch.float64, device=dev)
+    status = torch.zeros((S, Cn), dtype=torch.int32, device=dev)
+    wsb = lib.ivs_interp1d_workspace_bytes(TK, S, Cn)
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+    rc = lib.ivs_interp1d_batch_f64(_ptr(xk), _ptr(yk), TK, _ptr(knot_off), S, Cn, TK,
+                                    _ptr(xq), _ptr(q_off), total_q, _ptr(out), total_q, _ptr(status), code,
+                                    _ptr(ws), ws.numel() * 8, _stream(torch, stream))
+    _lib.check(rc, "ivs_interp1d_batch_f64")
+    return out, status
+
+
+def ffill_index_batch(src_pos, src_off, valid, q_off, total_q: int, stream=None):
+    """valid uint8 [n_cols, total_src] -> int32 [n_cols, total_q] flat source-row index or -1."""
+    torch = require_device()
+    lib = _lib.load()
+    n_cols, TS = valid.shape
+    S = src_off.numel() - 1
+    idx = torch.empty((n_cols, total_q), dtype=torch.int32, device=valid.device)
+    rc = lib.ivs_ffill_index_batch(_ptr(src_pos), _ptr(src_off), _ptr(valid.contiguous()), TS, n_cols, _ptr(q_off),
+                                   S, total_q, _ptr(idx), total_q, _stream(torch, stream))
+    _lib.check(rc, "ivs_ffill_index_batch")
+    return idx

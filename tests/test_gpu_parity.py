@@ -1,0 +1,210 @@
+"""GPU: the HIP path, called through the C ABI, against the oracle and the committed golden
+vectors.  Tolerances: 'linear' is BIT-EXACT (np.interp arithmetic reproduced); the spline methods
+are compared at rtol 1e-11 / atol 1e-12 against the oracle (measured ~1e-15) and at
+rtol 1e-12 / atol 1e-13 against the reference's golden outputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import ivs_oracle as O  # noqa: E402
+from golden_io import GOLDEN, SymbolCases, assert_symbol_frame  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR}
+RTOL, ATOL = 1e-11, 1e-12
+CASES = SymbolCases()
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, ref, method, what=""):
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern"
+    if method == "linear":
+        assert np.array_equal(got, ref, equal_nan=True), f"{what}: linear not bit-exact, max diff {np.nanmax(np.abs(got - ref))}"
+    else:
+        assert np.allclose(got, ref, rtol=RTOL, atol=ATOL, equal_nan=True), f"{what}: max diff {np.nanmax(np.abs(got - ref))}"
+
+
+def test_native_library_is_loaded():
+    from iv_interpolation_amd import _lib, engine
+    engine.require_device()
+    assert _lib.load().ivs_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libivs.so" in maps
+
+
+@pytest.mark.parametrize("name", CASES.names())
+def test_symbol_cases_on_gpu(name):
+    from iv_interpolation_amd import IVInterpolator
+    c = CASES.cases[name]
+    got = IVInterpolator(c["method"], c["min_points"]).interpolate_symbol(CASES.input(name))
+    lin = c["method"] in ("linear", "index", "values")
+    assert_symbol_frame(got, CASES.expected(name), rtol=0 if lin else 1e-12, atol=0 if lin else 1e-13, name=name)
+
+
+def test_symbol_batch_one_launch():
+    from iv_interpolation_amd import IVInterpolator
+    names = [n for n in CASES.names() if CASES.cases[n]["method"] == "cubic" and CASES.cases[n]["min_points"] == 2]
+    iv = IVInterpolator("cubic", 2)
+    got = iv.interpolate_batch([CASES.input(n) for n in names])
+    for n, g in zip(names, got):
+        assert_symbol_frame(g, CASES.expected(n), rtol=1e-12, atol=1e-13, name=n)
+
+
+def test_real1d_golden():
+    import torch
+    from iv_interpolation_amd import engine
+    g = np.load(os.path.join(GOLDEN, "real1d.npz"))
+    n = int(g["n_cases"])
+    xs = [g[f"c{k}/xk"] for k in range(n)]; ys = [g[f"c{k}/yk"] for k in range(n)]; qs = [g[f"c{k}/xq"] for k in range(n)]
+    koff = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+    qoff = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.int64)
+    for m in METHODS:
+        out, st = engine.interp1d_batch(dev(np.concatenate(xs)), dev(np.concatenate(ys)[None, :]), dev(koff), dev(qoff),
+                                        int(qoff[-1]), m, xq=dev(np.concatenate(qs)))
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()[0]; st = st.cpu().numpy()[:, 0]
+        for k in range(n):
+            got = out[qoff[k]:qoff[k + 1]]
+            if bool(g[f"c{k}/{m}_raised"]):
+                assert st[k] == O.ST_TOO_FEW_KNOTS and np.isnan(got).all()
+                continue
+            assert st[k] == O.ST_OK
+            exp = g[f"c{k}/{m}"]
+            assert np.array_equal(np.isnan(got), np.isnan(exp)), (k, m)
+            if m == "linear":
+                assert np.array_equal(got, exp, equal_nan=True), (k, m)
+            else:
+                assert np.allclose(got, exp, rtol=1e-12, atol=1e-13, equal_nan=True), (k, m, np.nanmax(np.abs(got - exp)))
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_surface_golden(force_generic):
+    from iv_interpolation_amd import engine
+    g = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    for k in range(int(g["n_cases"])):
+        K, T, s, Kq, Tq = [g[f"s{k}/{n}"] for n in ("K", "T", "sigma", "Kq", "Tq")]
+        for m in METHODS:
+            out, st = engine.surface_batch(dev(K[None]), dev(T), dev(s[None]), dev(Kq), dev(Tq), m, force_generic=force_generic)
+            got = out.cpu().numpy()[0]
+            if bool(g[f"s{k}/{m}_raised"]):
+                assert int(st.cpu()[0]) == O.ST_TOO_FEW_KNOTS
+                continue
+            exp = g[f"s{k}/{m}"]
+            assert np.array_equal(np.isnan(got), np.isnan(exp)), (k, m)
+            if m == "linear":
+                assert np.array_equal(got, exp, equal_nan=True), (k, m)
+            else:
+                assert np.allclose(got, exp, rtol=1e-12, atol=1e-13, equal_nan=True), (k, m, np.nanmax(np.abs(got - exp)))
+
+
+def _run(d, Kq, Tq, method, **kw):
+    from iv_interpolation_amd import engine
+    out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method, **kw)
+    return out.cpu().numpy(), st.cpu().numpy(), engine.last_kernel()
+
+
+@pytest.mark.parametrize("method", list(METHODS))
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_config2_10k_surfaces_vs_oracle(method, force_generic):
+    """BASELINE config 2: 10k synthetic snapshots, 64x16 -> 64x16, every surface compared."""
+    from iv_interpolation_amd import synth
+    d = synth.numpy_batch(10000, 64, 16, seed=synth.BASE_SEED)
+    Kq, Tq = synth.query_grids(64, 16)
+    got, st, kern = _run(d, Kq, Tq, method, force_generic=force_generic)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    assert np.array_equal(st, rst)
+    close(got, ref, method, f"config2 {method} [{kern}]")
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_config4_dense_output_grid(method):
+    from iv_interpolation_amd import synth
+    d = synth.numpy_batch(512, 64, 16, seed=synth.BASE_SEED + 4)
+    Kq, Tq = synth.query_grids(256, 64)
+    got, st, kern = _run(d, Kq, Tq, method)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    assert np.array_equal(st, rst)
+    close(got, ref, method, f"config4 {method} [{kern}]")
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_config1_shape_16x8(method):
+    from iv_interpolation_amd import synth
+    d = synth.numpy_batch(64, 16, 8, seed=synth.BASE_SEED + 1)
+    Kq, Tq = synth.query_grids(16, 8, nT=8)
+    got, st, kern = _run(d, Kq, Tq, method)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    close(got, ref, method, f"config1 {method} [{kern}]")
+
+
+@pytest.mark.parametrize("method", list(METHODS))
+def test_config5_ragged_vs_oracle(method):
+    from iv_interpolation_amd import engine, synth
+    d = synth.numpy_ragged_batch(400, 16, 8, 128, seed=synth.BASE_SEED + 5)
+    Kq, Tq = synth.query_grids(64, 16)
+    out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method,
+                                   k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=16)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method], k_off=d["k_off"])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    close(out.cpu().numpy(), ref, method, f"ragged {method}")
+
+
+@pytest.mark.parametrize("method", list(METHODS))
+def test_nan_masked_quotes_vs_oracle(method):
+    from iv_interpolation_amd import synth
+    d = synth.numpy_batch(300, 64, 16, seed=synth.BASE_SEED + 6, nan_frac=0.2)
+    d["sigma"][0, 3, :] = np.nan            # a whole row missing
+    d["sigma"][1, :, :61] = np.nan          # 3 knots per row: 'cubic' must flag too-few-knots
+    d["sigma"][2] = np.nan                  # an empty surface
+    Kq, Tq = synth.query_grids(64, 16)
+    got, st, kern = _run(d, Kq, Tq, method)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    assert np.array_equal(st, rst)
+    close(got, ref, method, f"nan {method} [{kern}]")
+
+
+def test_absolute_strikes_per_surface_query_grid():
+    from iv_interpolation_amd import engine, synth
+    d = synth.numpy_batch(200, 64, 16, seed=synth.BASE_SEED + 7, absolute=True)
+    Kq = d["S"][:, None] * np.linspace(0.72, 1.28, 64)[None, :]
+    Tq = synth.query_grids(64, 16)[1]
+    Tb = np.tile(d["T"], (200, 1))
+    for m in ("linear", "cubic"):
+        out, st = engine.surface_batch(dev(d["K"]), dev(Tb), dev(d["sigma"]), dev(Kq), dev(Tq), m)
+        ref, _ = O.surface_batch(d["K"], Tb, d["sigma"], Kq, Tq, METHODS[m])
+        close(out.cpu().numpy(), ref, m, f"absolute {m}")
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_full_size_properties_1M(method):
+    """BASELINE config 3 size (1M x 64x16), size-independent properties:
+    (a) querying at the knots reproduces the quotes; (b) a sample of surfaces equals the oracle;
+    (c) affine equivariance: f(a*sigma + c) == a*f(sigma) + c within tolerance."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    B = 1_000_000
+    d = synth.torch_batch(B, 64, 16, seed=synth.BASE_SEED)
+    Kq, Tq = synth.query_grids(64, 16)
+    out, st = engine.surface_batch(d["K"], d["T"], d["sigma"], dev(Kq), dev(Tq), method)
+    torch.cuda.synchronize()
+    assert int(st.max()) == 0 and not bool(torch.isnan(out).any())
+    idx = torch.arange(0, B, 4999, device="cuda")
+    ref, _ = O.surface_batch(d["K"][idx].cpu().numpy(), d["T"].cpu().numpy(), d["sigma"][idx].cpu().numpy(), Kq, Tq, METHODS[method])
+    close(out[idx].cpu().numpy(), ref, method, f"1M sample {method}")
+    out2, _ = engine.surface_batch(d["K"], d["T"], d["sigma"] * 2.0 + 0.25, dev(Kq), dev(Tq), method)
+    err = float((out2 - (out * 2.0 + 0.25)).abs().max())
+    assert err < 1e-11, err
+    del out2
+    # (a) knots reproduce: per-surface query grid = the surface's own strikes, Tq = T
+    sub = slice(0, 100_000)
+    outk, _ = engine.surface_batch(d["K"][sub], d["T"], d["sigma"][sub], d["K"][sub].contiguous(), d["T"], method)
+    err = float((outk - d["sigma"][sub]).abs().max())
+    assert err <= (0.0 if method == "linear" else 1e-12), err
