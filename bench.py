@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: IV surfaces/s on the BASELINE.json workload (1M snapshots, 64x16 quote grid
+-> 64x16 output grid, fp64), one process per GPU, batch sharded with no data-path collective.
+
+    python bench.py [--gpus N --steps K --warmup W] [--method cubic|linear|...] [--workload cfg3|cfg4|cfg5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (one ivs_surface_batch_f64 launch) over the rank's whole
+resident batch.  Inputs live in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Weak scaling: every rank holds `--batch` surfaces (default 1M), value = total surfaces / max-rank time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (nK, nT, mK, mT, ragged, description)
+    "cfg3": (64, 16, 64, 16, False, "1M snapshots x (64 strikes x 16 maturities) -> 64x16 output grid"),
+    "cfg4": (64, 16, 256, 64, False, "1M snapshots x (64x16) -> dense 256x64 output grid"),
+    "cfg5": (128, 16, 64, 16, True, "1M ragged snapshots, 8..128 strikes x 16 maturities -> 64x16"),
+}
+
+
+def algorithmic_bytes(B, nK, nT, mK, mT, total_strikes=None):
+    """per surface sigma nT*nK*8 + K nK*8 + T nT*8 in, mT*mK*8 out (query grids shared,
+    excluded); ragged adds the 8-byte CSR offset and uses the actual strike counts."""
+    if total_strikes is None:
+        return B * (8 * (nT * nK + nK + nT) + 8 * mT * mK)
+    return 8 * (nT * total_strikes + total_strikes + nT * B) + B * (8 * mT * mK + 8)
+
+
+def cpu_baseline(method, nK, nT, mK, mT, budget_s=20.0):
+    """The oracle ('port' of the reference's NumPy/SciPy arithmetic) timed on this box's host cores on a
+    bounded sample of the same workload.  Uses the compiled C oracle with OpenMP when it is built,
+    else the vectorised NumPy oracle on one core."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ivs_oracle as O
+    from iv_interpolation_amd import synth
+    code = O.METHOD_CODES[method]
+    Kq, Tq = synth.query_grids(mK, mT, nT)
+    try:
+        import c_oracle
+        runner = c_oracle.load()
+    except Exception:
+        runner = None
+    if runner is not None:
+        cores = runner.threads()
+        n = 20000
+        d = synth.numpy_batch(n, nK, nT, seed=synth.BASE_SEED)
+        runner.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, code)         # warm
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < budget_s / 2 or reps == 0:
+            runner.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, code); reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": n * reps / dt, "unit": "surfaces/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x {n} surfaces of the same generator, C oracle (oracle/ivs_oracle_c.c, OpenMP), method {method}"}
+    n = 2000
+    d = synth.numpy_batch(n, nK, nT, seed=synth.BASE_SEED)
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < budget_s / 2 or reps == 0:
+        O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, code); reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * reps / dt, "unit": "surfaces/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x {n} surfaces of the same generator, vectorised NumPy oracle (oracle/ivs_oracle.py), method {method}"}
+
+
+def load_traffic(workload, method, kernel):
+    """HBM bytes per launch from the committed PMC pass (profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(f"{workload}:{method}:{kernel}", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--method", default="cubic", choices=["linear", "cubic", "cubicspline", "slinear"])
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=1_000_000, help="surfaces per GPU (weak scaling)")
+    ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=256, help="surfaces compared with the oracle after the timed region")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from iv_interpolation_amd import engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    nK, nT, mK, mT, ragged, desc = WORKLOADS[a.workload]
+    B = a.batch
+    seed = synth.BASE_SEED + rank
+    Kq_h, Tq_h = synth.query_grids(mK, mT, nT)
+    Kq = torch.from_numpy(Kq_h).cuda(); Tq = torch.from_numpy(Tq_h).cuda()
+    if ragged:
+        d = synth.torch_ragged_batch(B, nT, 8, 128, seed=seed)
+        kw = dict(k_off=d["k_off"], nK_max=d["nK_max"], n_maturities=nT)
+        total_strikes = int(d["k_off"][-1])
+    else:
+        d = synth.torch_batch(B, nK, nT, seed=seed)
+        kw = {}
+        total_strikes = None
+    out = torch.empty((B, mT, mK), dtype=torch.float64, device="cuda")
+    status = torch.empty((B,), dtype=torch.int32, device="cuda")
+
+    def step():
+        engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, a.method, out=out, status=status,
+                             force_generic=a.force_generic, **kw)
+
+    for _ in range(a.warmup):
+        step()
+    kernel = engine.last_kernel()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = [s.elapsed_time(e) for s, e in ev]
+    if dist:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    assert int(status.max()) == 0
+
+    # parity spot check (outside the timed region): a few surfaces against the oracle
+    check = {}
+    if rank == 0 and a.check > 0 and not ragged:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ivs_oracle as O
+        idx = torch.linspace(0, B - 1, a.check, device="cuda").long()
+        ref, _ = O.surface_batch(d["K"][idx].cpu().numpy(), d["T"].cpu().numpy(), d["sigma"][idx].cpu().numpy(),
+                                 Kq_h, Tq_h, O.METHOD_CODES[a.method])
+        got = out[idx].cpu().numpy()
+        check = {"surfaces": a.check, "max_abs_diff_vs_oracle": float(np.nanmax(np.abs(got - ref))),
+                 "bit_exact": bool(np.array_equal(got, ref, equal_nan=True))}
+
+    if rank == 0:
+        total = B * world
+        bytes_launch = algorithmic_bytes(B, nK, nT, mK, mT, total_strikes)
+        avg_ms = sum(kern_ms) / len(kern_ms)
+        achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+        res = {
+            "metric": "IV surfaces/sec (1M-batch, 64x16 grid)", "value": total * a.steps / wall, "unit": "surfaces/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {desc}", "method": a.method, "surfaces_per_gpu": B,
+                       "quote_grid": [nK, nT], "output_grid": [mK, mT], "kernel": kernel,
+                       "sharding": f"{world} x contiguous shard, no collective", "seed": synth.BASE_SEED},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(a.workload, a.method, kernel),
+                         "kernel": kernel, "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms),
+                         "algorithmic_bytes_per_launch": bytes_launch, "timing": "HIP events around each launch on the launch stream"},
+            "parity_check": check,
+        }
+        if world == 1 and not a.no_cpu_baseline and not ragged:
+            res["cpu_baseline"] = cpu_baseline(a.method, nK, nT, mK, mT)
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
