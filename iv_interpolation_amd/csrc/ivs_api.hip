@@ -158,22 +158,10 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
         if (rc < 0) return fail(IVS_ELAUNCH, "ivs_surface_batch_f64: dense dispatch failed");
     }
 
-    size_t lds = ivs::generic_lds_bytes(nK, nT);
-    if (lds > 160 * 1024)
-        return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d x nT=%d needs %zu B of LDS (> 160 KiB)", nK, nT, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ivs::surface_generic_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 16) per_cu = 16;
-    int64_t grid = (int64_t)num_cu() * per_cu * 2;
-    if (grid > B) grid = B;
+    if (!ivs::launch_surface_generic<false>(p, num_cu(), st))
+        return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d x nT=%d needs %zu B of LDS (> 160 KiB)", nK, nT,
+                    ivs::generic_lds_bytes(nK, nT));
     g_last_kernel = "surface_generic_kernel";
-    hipLaunchKernelGGL(ivs::surface_generic_kernel, dim3((unsigned)grid), dim3(64), lds, st, p);
     return check_launch("surface_generic_kernel");
 }
 
