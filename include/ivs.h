@@ -115,6 +115,16 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
 /* name of the kernel the last ivs_surface_batch_f64 call on this thread dispatched to (host string) */
 const char* ivs_last_kernel(void);
 
+/*
+ * Diagnostics (not part of the drop-in surface).  ivs_debug_stamps(buf, n): while `buf` (device,
+ * n uint64, n >= 8 * 8 * CU count) is set, ivs_surface_batch_f64 runs the STAMPED build of the dense
+ * kernel, which sums s_memtime deltas per phase and per workgroup into buf[wg*8 + phase]
+ * (phase 7 = surfaces processed).  Pass NULL to return to the production kernel.  Returns the
+ * number of slots per workgroup.  Stamped runs are for phase SHARES only, never for timing claims.
+ */
+int     ivs_debug_stamps(void* device_buf, int64_t n_u64);
+int64_t ivs_debug_last_grid(void);   /* workgroups of the last dense launch */
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,9 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local const char* g_last_kernel = "";
+unsigned long long* g_stamp_buf = nullptr;   // device buffer for the diagnostic (stamped) dense kernel
+int64_t g_stamp_cap = 0;
+int64_t g_last_grid = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -53,6 +56,14 @@ int ivs_version(void) { return IVS_ABI_VERSION; }
 const char* ivs_last_error(void) { return g_err; }
 
 const char* ivs_last_kernel(void) { return g_last_kernel; }
+
+int ivs_debug_stamps(void* device_buf, int64_t n_u64) {
+    g_stamp_buf = static_cast<unsigned long long*>(device_buf);
+    g_stamp_cap = device_buf ? n_u64 : 0;
+    return (int)ivs::D_NSTAMP;
+}
+
+int64_t ivs_debug_last_grid(void) { return g_last_grid; }
 
 int ivs_device_count(void) {
     int n = 0;
@@ -150,7 +161,9 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
 
     if (!(flags & IVS_FLAG_FORCE_GENERIC)) {
         const char* name = nullptr;
-        int rc = ivs::launch_surface_dense(p, num_cu(), st, &name);
+        int64_t need_blocks = (int64_t)num_cu() * 8;
+        unsigned long long* dbg = (g_stamp_buf && g_stamp_cap >= need_blocks * ivs::D_NSTAMP) ? g_stamp_buf : nullptr;
+        int rc = ivs::launch_surface_dense(p, num_cu(), st, &name, dbg, &g_last_grid);
         if (rc == 1) {   // dispatched
             g_last_kernel = name;
             return check_launch(name);

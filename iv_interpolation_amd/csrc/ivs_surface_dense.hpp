@@ -22,17 +22,97 @@ namespace ivs {
 
 constexpr int DK = 64, DT = 16;
 constexpr int D_RS = 72;                         // row stride in doubles (4 x (16 + 2))
+constexpr int D_MAX_MT = 64;                     // query maturities per surface handled by the dense kernel
 constexpr unsigned long long D_SENTINEL = REDO_SENTINEL;           // NaN payload = "redo generically"
 
 __device__ __forceinline__ int d_sl(int k) { return (k >> 4) * 18 + (k & 15); }
 
-__host__ __device__ inline size_t dense_lds_bytes(int mT) {
-    // Y, S planes; Ksh, RDX, AL, CP, PP, QQ, PI, PSI (64 each); Tsh + T tables [16][4]; W [mT][4]; CNT
-    return (size_t)(2 * DT * D_RS + 8 * 64 + 16 + 64 + 4 * (size_t)mT) * 8 + 32 * 4;
+__host__ __device__ inline size_t dense_lds_bytes() {
+    // Y, S planes (the strike tables AL..PSI alias the S plane); Ksh, RDX; Tsh; TT [16][4]
+    return (size_t)(2 * DT * D_RS + 64 + 64 + 16 + 64) * 8;
 }
 
 // codes of a query row in the maturity direction
 constexpr int TQ_LEFT = -1, TQ_HOLD = 15, TQ_NAN = 16;
+
+// ---- cross-lane helpers (DPP moves stay in the VALU; ds_bpermute shuffles cost an LDS round trip)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHL(int n) { return 0x100 | n; }   // lane i <- lane i+n (within a row of 16)
+constexpr int DPP_ROW_SHR(int n) { return 0x110 | n; }   // lane i <- lane i-n (within a row of 16)
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/b to <= 1 ulp: v_rcp_f64 + two Newton steps (the reciprocal the IEEE division expansion uses)
+__device__ __forceinline__ double refined_rcp(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// exponent of |x| inside [2^-500, 2^500]: the range where the division expansion applies no scaling
+__device__ __forceinline__ bool div_safe(double x) {
+    const double ax = __builtin_fabs(x);
+    return ax >= 0x1p-500 && ax <= 0x1p500;
+}
+// Correctly rounded a/b from y = refined_rcp(b): q = a*y, r = a - q*b, q' = q + r*y.  This IS the tail of
+// the hardware IEEE expansion (v_div_scale is the identity in the safe range), so results are bit-identical
+// to `a / b` there; outside it (or for non-finite operands) fall back to the full division.
+__device__ __forceinline__ double div_shared_rcp(double a, double b, double y, bool b_safe) {
+    const double q = a * y;
+    const double r = __builtin_fma(-q, b, a);
+    double res = __builtin_fma(r, y, q);
+    if (__builtin_expect(!(b_safe && (a == 0.0 || div_safe(a))), 0)) res = a / b;
+    return res;
+}
+// np.interp's interior formula with the shared-reciprocal division (bit-exact, see lerp_np)
+__device__ __forceinline__ double lerp_np_rcp(double xq, double x0, double y0, double x1, double y1, double dx,
+                                              double rdx, bool dx_safe) {
+#pragma clang fp contract(off)
+    if (x0 == xq) return y0;
+    const double slope = div_shared_rcp(y1 - y0, dx, rdx, dx_safe);
+    double r = slope * (xq - x0) + y0;
+    if (__builtin_isnan(r)) {
+        r = slope * (xq - x1) + y1;
+        if (__builtin_isnan(r) && y0 == y1) r = y0;
+    }
+    return r;
+}
+
+// Inclusive scan over lanes 0..N-1 (N = 16 or 64) of 2x2 matrix products P_i <- P_i * P_{i-1} * ... * P_0.
+template <int N>
+__device__ __forceinline__ void scan_mat2(double& p00, double& p01, double& p10, double& p11, int lane) {
+#define IVS_SCAN_STEP(CTRL, MASK, COND)                                                        \
+    {                                                                                          \
+        const double e = dpp_f64<CTRL, MASK>(p00, p00), f = dpp_f64<CTRL, MASK>(p01, p01);     \
+        const double g = dpp_f64<CTRL, MASK>(p10, p10), h = dpp_f64<CTRL, MASK>(p11, p11);     \
+        if (COND) {                                                                            \
+            const double n00 = p00 * e + p01 * g, n01 = p00 * f + p01 * h;                     \
+            const double n10 = p10 * e + p11 * g, n11 = p10 * f + p11 * h;                     \
+            p00 = n00; p01 = n01; p10 = n10; p11 = n11;                                        \
+        }                                                                                      \
+    }
+    const int r = lane & 15;
+    IVS_SCAN_STEP(DPP_ROW_SHR(1), 0xF, r >= 1)
+    IVS_SCAN_STEP(DPP_ROW_SHR(2), 0xF, r >= 2)
+    IVS_SCAN_STEP(DPP_ROW_SHR(4), 0xF, r >= 4)
+    IVS_SCAN_STEP(DPP_ROW_SHR(8), 0xF, r >= 8)
+    if (N > 16) {
+        IVS_SCAN_STEP(DPP_ROW_BCAST15, 0xA, (lane & 16) != 0)     // rows 1,3 <- lane 15 of rows 0,2
+        IVS_SCAN_STEP(DPP_ROW_BCAST31, 0xC, lane >= 32)           // rows 2,3 <- lane 31
+    }
+#undef IVS_SCAN_STEP
+}
 
 // Factorisation tables of the not-a-knot slope system on N knots X[0..N) (N = 64 or 16), computed by
 // lanes 0..N-1.  Conventions (oracle nak_slopes()):  forward  dp_i = PP_i*dyA + QQ_i*dyB - AL_i*dp_{i-1},
@@ -51,40 +131,36 @@ __device__ __forceinline__ void factor_tables(const double* X, int lane, double&
     const double dxm = x0 - xm;          // dx[i-1]
     const double dxp = xpp - xp;         // dx[i+1]
     const double dxmm = xm - xmm;        // dx[i-2]
-    const double rdxc = 1.0 / dxc;
+    const double rdxc = refined_rcp(dxc);
     double a, b, c;
     if (i == 0) { a = 0.0; b = dxp; c = dxc + dxp; }
     else if (i == N - 1) { a = dxmm + dxm; b = dxmm; c = 0.0; }
     else { a = dxc; b = 2.0 * (dxm + dxc); c = dxm; }
+    const double rb = refined_rcp(b);
     // g_i = a_i c_{i-1} / (b_i b_{i-1})
-    const double c_prev = __shfl_up(c, 1);
-    const double b_prev = __shfl_up(b, 1);
-    const double g = i == 0 ? 0.0 : (a * c_prev) / (b * b_prev);
+    const double crb = c * rb;                                          // c_i / b_i
+    const double crb_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, crb);
+    const double g = i == 0 ? 0.0 : a * rb * crb_prev;
     // omega_i = 1 - g_i / omega_{i-1}: prefix product of M_i = [[1,-g_i],[1,0]] (identity on lane 0)
     double p00 = 1.0, p01 = i == 0 ? 0.0 : -g, p10 = i == 0 ? 0.0 : 1.0, p11 = i == 0 ? 1.0 : 0.0;
-#pragma unroll
-    for (int s = 1; s < N; s <<= 1) {
-        const double e = __shfl_up(p00, s), f = __shfl_up(p01, s), gg = __shfl_up(p10, s), h = __shfl_up(p11, s);
-        if (i >= s) {
-            const double n00 = p00 * e + p01 * gg, n01 = p00 * f + p01 * h;
-            const double n10 = p10 * e + p11 * gg, n11 = p10 * f + p11 * h;
-            p00 = n00; p01 = n01; p10 = n10; p11 = n11;
-        }
-    }
+    scan_mat2<N>(p00, p01, p10, p11, lane);
     const double num = p00 + p01, den = p10 + p11;          // omega_i = num / den (applied to omega_0 = 1)
-    const double rw = i == 0 ? 1.0 / b : den / (b * num);   // 1 / w_i
+    const double rw = i == 0 ? rb : den * rb * refined_rcp(num);   // 1 / w_i
     al = a * rw;
     cp = c * rw;
-    const double rdx_prev = __shfl_up(rdxc, 1);             // 1/dx[i-1]
-    const double rdx_next = __shfl_down(rdxc, 1);           // 1/dx[i+1]
+    const double rdx_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, rdxc);   // 1/dx[i-1]
+    const double rdx_next = dpp_f64<DPP_WAVE_SHL1>(0.0, rdxc);   // 1/dx[i+1]
+    // (DPP reads need the SOURCE lane active: keep every cross-lane move outside divergent branches)
+    const double rdxmm = dpp_f64<DPP_WAVE_SHR1>(0.0, rdx_prev);  // 1/dx[i-2]
+    // edge rows need 1/d with d = x_{i+2}-x_i (row 0) or x_i - x_{i-2} (row N-1)
+    const double d = i == 0 ? dxc + dxp : dxmm + dxm;
+    const double rd = refined_rcp(d);
     if (i == 0) {
-        const double d = dxc + dxp;
-        pp = (dxc + 2.0 * d) * dxp * rdxc / d * rw;          // * dy_0
-        qq = dxc * dxc * rdx_next / d * rw;                  // * dy_1
+        pp = (dxc + 2.0 * d) * dxp * rdxc * rd * rw;         // * dy_0
+        qq = dxc * dxc * rdx_next * rd * rw;                 // * dy_1
     } else if (i == N - 1) {
-        const double d = dxmm + dxm;
-        pp = dxm * dxm / (dxmm * d) * rw;                    // * dy_{N-3}
-        qq = (2.0 * d + dxm) * dxmm / (dxm * d) * rw;        // * dy_{N-2}
+        pp = dxm * dxm * rdxmm * rd * rw;                    // * dy_{N-3}
+        qq = (2.0 * d + dxm) * dxmm * rdx_prev * rd * rw;    // * dy_{N-2}
     } else {
         pp = 3.0 * dxc * rdx_prev * rw;                      // * dy_{i-1}
         qq = 3.0 * dxm * rdxc * rw;                          // * dy_i
@@ -92,27 +168,133 @@ __device__ __forceinline__ void factor_tables(const double* X, int lane, double&
     rdx_out = rdxc;
 }
 
-// segmented inclusive prefix product within aligned groups of 16 lanes (towards higher lanes)
+// segmented inclusive prefix / suffix products within aligned rows of 16 lanes
 __device__ __forceinline__ double seg16_prefix_prod(double v, int lane) {
-#pragma unroll
-    for (int s = 1; s < 16; s <<= 1) {
-        const double o = __shfl_up(v, s);
-        if ((lane & 15) >= s) v *= o;
-    }
+    const int r = lane & 15;
+    double o;
+    o = dpp_f64<DPP_ROW_SHR(1)>(1.0, v); if (r >= 1) v *= o;
+    o = dpp_f64<DPP_ROW_SHR(2)>(1.0, v); if (r >= 2) v *= o;
+    o = dpp_f64<DPP_ROW_SHR(4)>(1.0, v); if (r >= 4) v *= o;
+    o = dpp_f64<DPP_ROW_SHR(8)>(1.0, v); if (r >= 8) v *= o;
     return v;
 }
 __device__ __forceinline__ double seg16_suffix_prod(double v, int lane) {
-#pragma unroll
-    for (int s = 1; s < 16; s <<= 1) {
-        const double o = __shfl_down(v, s);
-        if ((lane & 15) + s < 16) v *= o;
-    }
+    const int r = lane & 15;
+    double o;
+    o = dpp_f64<DPP_ROW_SHL(1)>(1.0, v); if (r + 1 < 16) v *= o;
+    o = dpp_f64<DPP_ROW_SHL(2)>(1.0, v); if (r + 2 < 16) v *= o;
+    o = dpp_f64<DPP_ROW_SHL(4)>(1.0, v); if (r + 4 < 16) v *= o;
+    o = dpp_f64<DPP_ROW_SHL(8)>(1.0, v); if (r + 8 < 16) v *= o;
     return v;
 }
 
-template <int METHOD>
-__global__ __launch_bounds__(64) void surface_dense_kernel(SurfaceParams p) {
+// Strike-direction slopes of all 16 rows of the staged surface: K-phase (k-lane factorisation) followed by
+// the segmented sweeps (rs-lane).  Reads Y and Ksh, writes RDX and (last) the S plane; the factor tables
+// live in the S plane until then.  Must be called by all 64 lanes of the workgroup.
+template <bool STAMPED, class StampFn>
+__device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, const double* Ksh, double* RDX,
+                                                    int lane, StampFn&& stamp) {
+    double* AL = S;                    // strike tables alias the S plane: dead before S is written
+    double* CP = S + 64;
+    double* PP = S + 128;
+    double* QQ = S + 192;
+    double* PI = S + 256;
+    double* PSI = S + 320;
+    const int rs_t = lane >> 2, rs_seg = lane & 3;
+    // ---- K-phase (k-lane)
+    double al, cp, pp, qq, rdx;
+    factor_tables<DK>(Ksh, lane, al, cp, pp, qq, rdx);
+    AL[lane] = al; CP[lane] = cp; PP[lane] = pp; QQ[lane] = qq; RDX[lane] = rdx;
+    PI[lane] = seg16_prefix_prod(-al, lane);       // prod_{seg start..i} (-AL)
+    PSI[lane] = seg16_suffix_prod(-cp, lane);      // prod_{i..seg end} (-CP)
+    __syncthreads();
+    if (STAMPED) stamp(1);
+    // ---- strike sweeps (rs-lane): row rs_t, knots rs_seg*16 .. +15
+    const double* yrow = Y + rs_t * D_RS + rs_seg * 18;
+    const int kb = rs_seg * 16;
+    double y[18];                                  // y[m+1] = y_{kb+m}, m = -1..16
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(yrow + 2 * c);
+        y[1 + 2 * c] = v.x; y[2 + 2 * c] = v.y;
+    }
+    y[0] = rs_seg > 0 ? Y[rs_t * D_RS + d_sl(kb - 1)] : 0.0;
+    y[17] = rs_seg < 3 ? Y[rs_t * D_RS + d_sl(kb + 16)] : 0.0;
+    // dy(m) = y_{kb+m} - y_{kb+m-1} = y[m+1] - y[m]
+    double d[16];
+    double prev = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        double dA = y[m + 1] - y[m], dB = y[m + 2] - y[m + 1];         // (dy_{i-1}, dy_i)
+        if (m == 0) { const double e = y[3] - y[2]; dA = rs_seg == 0 ? dB : dA; dB = rs_seg == 0 ? e : dB; }
+        if (m == 15) { const double e = y[15] - y[14]; dB = rs_seg == 3 ? dA : dB; dA = rs_seg == 3 ? e : dA; }
+        const double r = PP[kb + m] * dA + QQ[kb + m] * dB;
+        prev = r - AL[kb + m] * prev;
+        d[m] = prev;
+        if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // carry across the 4 segments of the row (lanes 4t..4t+3 sit in one DPP row)
+    const double pie = PI[kb + 15];
+    double din = 0.0, tot = d[15];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const double v = dpp_f64<DPP_ROW_SHR(1)>(0.0, tot);
+        if (rs_seg == j) { din = v; tot = d[15] + pie * din; }
+    }
+    double nxt = 0.0;
+#pragma unroll
+    for (int m = 15; m >= 0; --m) {
+        const double dp = d[m] + PI[kb + m] * din;
+        nxt = dp - CP[kb + m] * nxt;
+        d[m] = nxt;                                // local backward solution
+        if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    const double psb = PSI[kb];
+    double sin_ = 0.0;
+    tot = d[0];
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+        const double v = dpp_f64<DPP_ROW_SHL(1)>(0.0, tot);
+        if (rs_seg == j) { sin_ = v; tot = d[0] + psb * sin_; }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) d[m] = d[m] + PSI[kb + m] * sin_;
+    __syncthreads();                               // all table reads done: the S plane may be overwritten
+    double* srow = S + rs_t * D_RS + rs_seg * 18;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
+        *reinterpret_cast<double2*>(srow + 2 * c) = v;
+    }
+}
+
+// STAMP = true is the diagnostic build (ivs_debug_stamps): s_memtime deltas per phase are summed per
+// workgroup into a debug buffer; never used for timing claims (the stamps serialise the phases).
+constexpr int D_NSTAMP = 8;   // stage, k-phase, sweeps, strike-eval, maturity-solve, maturity-eval+store, (unused), surfaces
+
+// What the T-phase leaves in registers: per-query-row weights in lane = tq, row counts per class (uniform).
+struct TqTables {
+    double w0, w1, w2, w3;
+    int n_left, n_hold, n_nan, unsorted;
+    unsigned long long iv_lo, iv_hi;      // rows per interval 0..7 / 8..14, one byte each
+    __device__ __forceinline__ int n_iv(int j) const { return (int)(((j < 8 ? iv_lo : iv_hi) >> (8 * (j & 7))) & 0xffull); }
+};
+
+template <int METHOD, bool TSHARED, bool STAMP = false>
+__global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, unsigned long long* dbg = nullptr) {
     constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    unsigned long long acc[D_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    auto stamp = [&](int i) {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tn = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (i >= 0) acc[i] += tn - tprev;
+            tprev = tn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
@@ -120,21 +302,14 @@ __global__ __launch_bounds__(64) void surface_dense_kernel(SurfaceParams p) {
     double* S = Y + DT * D_RS;
     double* Ksh = S + DT * D_RS;
     double* RDX = Ksh + 64;
-    double* AL = RDX + 64;
-    double* CP = AL + 64;
-    double* PP = CP + 64;
-    double* QQ = PP + 64;
-    double* PI = QQ + 64;
-    double* PSI = PI + 64;
-    double* Tsh = PSI + 64;            // 16
+    double* Tsh = RDX + 64;            // 16
     double* TT = Tsh + 16;             // [16][4] = {PP, QQ, AL, CP} of the maturity system
-    double* W = TT + 64;               // [mT][4]
-    int* CNT = reinterpret_cast<int*>(W + 4 * (size_t)mT);   // [0]=left, [1..15]=interval 0..14, [16]=hold, [17]=nan, [18]=unsorted
 
-    const bool t_shared = p.t_stride == 0 && p.tq_stride == 0;
-    const int rs_t = lane >> 2, rs_seg = lane & 3;
+    constexpr bool t_shared = TSHARED;   // T and Tq shared by the whole batch: T-phase hoisted out of the loop
+    const double nanv = __builtin_nan("");
 
-    // ---- T-phase: maturity-direction tables + per-query-row weights
+    // ---- T-phase: maturity-direction tables (LDS) + per-query-row weights (registers, lane = tq)
+    TqTables tt;
     auto t_phase = [&](const double* Tb, const double* Tqb) {
         if (lane < DT) Tsh[lane] = Tb[lane];
         __syncthreads();
@@ -143,61 +318,47 @@ __global__ __launch_bounds__(64) void surface_dense_kernel(SurfaceParams p) {
             factor_tables<DT>(Tsh, lane, al, cp, pp, qq, rdx);
             if (lane < DT) { TT[lane * 4 + 0] = pp; TT[lane * 4 + 1] = qq; TT[lane * 4 + 2] = al; TT[lane * 4 + 3] = cp; }
         }
-        int c_left = 0, c_hold = 0, c_nan = 0, unsorted = 0;
-        int c_iv[15];
+        const int tq = lane;
+        const bool act = tq < mT;
+        const double x = act ? Tqb[tq] : __builtin_inf();
+        int j = -1;                                           // largest j with Tsh[j] <= x, or -1
+        if (Tsh[0] <= x) {
+            j = 0;
 #pragma unroll
-        for (int j = 0; j < 15; ++j) c_iv[j] = 0;
-        double carry = -__builtin_inf();
-        for (int q0 = 0; q0 < mT; q0 += 64) {
-            const int tq = q0 + lane;
-            const bool act = tq < mT;
-            const double x = act ? Tqb[tq] : __builtin_inf();
-            // largest j with Tsh[j] <= x, or -1
-            int j = -1;
-            if (Tsh[0] <= x) {
-                j = 0;
-#pragma unroll
-                for (int st = 8; st >= 1; st >>= 1) if (Tsh[j + st] <= x) j += st;
-            }
-            int code;
-            const double tl = Tsh[DT - 1];
-            if (j < 0) code = TQ_LEFT;
-            else if (j >= DT - 1) {
-                if (METHOD == IVS_LINEAR) code = TQ_HOLD;
-                else if (METHOD == IVS_SLINEAR) code = (x == tl) ? TQ_HOLD : TQ_NAN;
-                else if (METHOD == IVS_CUBIC) code = (x == tl) ? DT - 2 : TQ_NAN;
-                else code = DT - 2;
-            } else code = j;
-            if (!(x == x)) code = TQ_LEFT;                    // NaN query -> NaN row
-            if (act) {
-                const int jj = code >= 0 && code <= DT - 2 ? code : 0;
-                const double x0 = Tsh[jj], x1 = Tsh[jj + 1];
-                double w0, w1, w2, w3;
-                if (CUB) {
-                    const double h = x1 - x0, u = x - x0, t = u / h, omt = 1.0 - t;
-                    w0 = (1.0 + 2.0 * t) * omt * omt;         // h00
-                    w1 = t * t * (3.0 - 2.0 * t);             // h01
-                    w2 = u * omt * omt;                       // h * h10
-                    w3 = u * t * (t - 1.0);                   // h * h11
-                } else { w0 = x; w1 = x0; w2 = x1; w3 = 0.0; }
-                W[tq * 4 + 0] = w0; W[tq * 4 + 1] = w1; W[tq * 4 + 2] = w2; W[tq * 4 + 3] = w3;
-            }
-            c_left += __popcll(__ballot(act && code == TQ_LEFT));
-            c_hold += __popcll(__ballot(act && code == TQ_HOLD));
-            c_nan += __popcll(__ballot(act && code == TQ_NAN));
-#pragma unroll
-            for (int jv = 0; jv < 15; ++jv) c_iv[jv] += __popcll(__ballot(act && code == jv));
-            // ascending check (codes must come out grouped: left, 0..14, hold/nan)
-            double xprev = __shfl_up(x, 1);
-            if (lane == 0) xprev = carry;
-            unsorted |= __ballot(act && ((x < xprev) || !(x == x))) != 0ull;
-            carry = __shfl(x, 63);
+            for (int st = 8; st >= 1; st >>= 1) if (Tsh[j + st] <= x) j += st;
         }
-        if (lane == 0) {
-            CNT[0] = c_left; CNT[16] = c_hold; CNT[17] = c_nan; CNT[18] = unsorted;
-#pragma unroll
-            for (int jv = 0; jv < 15; ++jv) CNT[1 + jv] = c_iv[jv];
+        int code;
+        const double tl = Tsh[DT - 1];
+        if (j < 0) code = TQ_LEFT;
+        else if (j >= DT - 1) {
+            if (METHOD == IVS_LINEAR) code = TQ_HOLD;
+            else if (METHOD == IVS_SLINEAR) code = (x == tl) ? TQ_HOLD : TQ_NAN;
+            else if (METHOD == IVS_CUBIC) code = (x == tl) ? DT - 2 : TQ_NAN;
+            else code = DT - 2;
+        } else code = j;
+        const int jj = code >= 0 && code <= DT - 2 ? code : 0;
+        const double x0 = Tsh[jj], x1 = Tsh[jj + 1];
+        if (CUB) {
+            const double h = x1 - x0, u = x - x0, t = u / h, omt = 1.0 - t;
+            tt.w0 = (1.0 + 2.0 * t) * omt * omt;              // h00
+            tt.w1 = t * t * (3.0 - 2.0 * t);                  // h01
+            tt.w2 = u * omt * omt;                            // h * h10
+            tt.w3 = u * t * (t - 1.0);                        // h * h11
+        } else {
+            tt.w0 = x; tt.w1 = x0; tt.w2 = x1; tt.w3 = refined_rcp(x1 - x0);
         }
+        tt.n_left = __popcll(__ballot(act && code == TQ_LEFT));
+        tt.n_hold = __popcll(__ballot(act && code == TQ_HOLD));
+        tt.n_nan = __popcll(__ballot(act && code == TQ_NAN));
+        tt.iv_lo = 0; tt.iv_hi = 0;
+#pragma unroll
+        for (int jv = 0; jv < DT - 1; ++jv) {
+            const unsigned long long n = (unsigned long long)__popcll(__ballot(act && code == jv));
+            if (jv < 8) tt.iv_lo |= n << (8 * jv); else tt.iv_hi |= n << (8 * (jv - 8));
+        }
+        // the row loops below walk the classes in order: needs ascending, NaN-free Tq
+        const double xprev = dpp_f64<DPP_WAVE_SHR1>(-__builtin_inf(), x);
+        tt.unsorted = __ballot(act && ((x < xprev) || !(x == x))) != 0ull;
         __syncthreads();
     };
 
@@ -207,8 +368,7 @@ __global__ __launch_bounds__(64) void surface_dense_kernel(SurfaceParams p) {
     double2 pre[8];
     double pre_k;
     auto prefetch = [&](int64_t b) {
-        const double* sb = p.sigma + b * (int64_t)(DT * DK);
-        const double2* s2 = reinterpret_cast<const double2*>(sb);
+        const double2* s2 = reinterpret_cast<const double2*>(p.sigma + b * (int64_t)(DT * DK));
 #pragma unroll
         for (int i = 0; i < 8; ++i) pre[i] = s2[i * 64 + lane];
         pre_k = p.K[b * p.k_stride + lane];
@@ -218,6 +378,7 @@ __global__ __launch_bounds__(64) void surface_dense_kernel(SurfaceParams p) {
 
     for (; b < p.B; b += gridDim.x) {
         __syncthreads();                                   // everyone is done reading the previous surface's LDS
+        stamp(-1);
         // ---- stage quotes: chunk i, lane -> row t = 2i + (lane>>5), k = 2*(lane&31)
         bool bad = false;
 #pragma unroll
@@ -227,176 +388,126 @@ __global__ __launch_bounds__(64) void surface_dense_kernel(SurfaceParams p) {
             bad |= !(pre[i].x == pre[i].x) || !(pre[i].y == pre[i].y);
         }
         Ksh[lane] = pre_k;
-        const int64_t bn = b + gridDim.x;
-        if (bn < p.B) prefetch(bn);                        // next surface's loads fly during this one's math
         double* outb = p.out + b * (int64_t)mT * mK;
         if (!t_shared) t_phase(p.T + b * p.t_stride, p.Tq + b * p.tq_stride);   // contains a barrier
-        const bool redo = __ballot(bad) != 0ull || CNT[18] != 0;
-        if (redo) {                                        // wave-uniform
+        if (__ballot(bad) != 0ull || tt.unsorted) {        // wave-uniform: leave it to the generic kernel
             if (lane == 0) reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;
+            if (b + gridDim.x < p.B) prefetch(b + gridDim.x);
             continue;
         }
         __syncthreads();
+        stamp(0);
         if (CUB) {
-            // ---- K-phase (k-lane)
-            double al, cp, pp, qq, rdx;
-            factor_tables<DK>(Ksh, lane, al, cp, pp, qq, rdx);
-            AL[lane] = al; CP[lane] = cp; PP[lane] = pp; QQ[lane] = qq; RDX[lane] = rdx;
-            PI[lane] = seg16_prefix_prod(-al, lane);       // prod_{seg start..i} (-AL)
-            PSI[lane] = seg16_suffix_prod(-cp, lane);      // prod_{i..seg end} (-CP)
+            dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
             __syncthreads();
-            // ---- strike sweeps (rs-lane): row rs_t, knots rs_seg*16 .. +15
-            const double* yrow = Y + rs_t * D_RS + rs_seg * 18;
-            const int kb = rs_seg * 16;
-            double y[18];                                  // y[m+1] = y_{kb+m}, m = -1..16
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const double2 v = *reinterpret_cast<const double2*>(yrow + 2 * c);
-                y[1 + 2 * c] = v.x; y[2 + 2 * c] = v.y;
-            }
-            y[0] = rs_seg > 0 ? Y[rs_t * D_RS + d_sl(kb - 1)] : 0.0;
-            y[17] = rs_seg < 3 ? Y[rs_t * D_RS + d_sl(kb + 16)] : 0.0;
-            double dy[17];                                 // dy[m+1] = y_{kb+m+1} - y_{kb+m}, m = -1..15
-#pragma unroll
-            for (int m = 0; m < 17; ++m) dy[m] = y[m + 1] - y[m];
-            double d[16];
-            double prev = 0.0;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                double dA = dy[m], dB = dy[m + 1];         // (dy_{i-1}, dy_i)
-                if (m == 0) { dA = rs_seg == 0 ? dy[1] : dy[0]; dB = rs_seg == 0 ? dy[2] : dy[1]; }
-                if (m == 15) { dA = rs_seg == 3 ? dy[14] : dy[15]; dB = rs_seg == 3 ? dy[15] : dy[16]; }
-                const double r = PP[kb + m] * dA + QQ[kb + m] * dB;
-                prev = r - AL[kb + m] * prev;
-                d[m] = prev;
-            }
-            // carry across the 4 segments of the row
-            const double pie = PI[kb + 15];
-            double din = 0.0, tot = d[15];
-#pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                const double v = __shfl_up(tot, 1);
-                if (rs_seg == j) { din = v; tot = d[15] + pie * din; }
-            }
-            double nxt = 0.0;
-#pragma unroll
-            for (int m = 15; m >= 0; --m) {
-                const double dp = d[m] + PI[kb + m] * din;
-                nxt = dp - CP[kb + m] * nxt;
-                d[m] = nxt;                                // local backward solution
-            }
-            const double psb = PSI[kb];
-            double sin_ = 0.0;
-            tot = d[0];
-#pragma unroll
-            for (int j = 2; j >= 0; --j) {
-                const double v = __shfl_down(tot, 1);
-                if (rs_seg == j) { sin_ = v; tot = d[0] + psb * sin_; }
-            }
-            double* srow = S + rs_t * D_RS + rs_seg * 18;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                double2 v;
-                v.x = d[2 * c] + PSI[kb + 2 * c] * sin_;
-                v.y = d[2 * c + 1] + PSI[kb + 2 * c + 1] * sin_;
-                *reinterpret_cast<double2*>(srow + 2 * c) = v;
-            }
-            __syncthreads();
+            stamp(2);
         }
-        // counts of query rows per maturity interval -> scalar registers
-        const int n_left = __builtin_amdgcn_readfirstlane(CNT[0]);
-        const int n_hold = __builtin_amdgcn_readfirstlane(CNT[16]);
-        const int n_nan = __builtin_amdgcn_readfirstlane(CNT[17]);
 
+        {
+            const int64_t bn = b + gridDim.x;
+            if (bn < p.B) prefetch(bn);                    // next surface's loads fly during evaluation + maturity pass
+        }
         const double* Kqb = p.Kq + b * p.kq_stride;
         for (int q0 = 0; q0 < mK; q0 += 64) {
             const int q = q0 + lane;
             const bool act = q < mK;
-            const double xq = act ? Kqb[q] : __builtin_nan("");
-            // ---- strike evaluation (q-lane)
-            int j = -1;
-            if (Ksh[0] <= xq) {
-                j = 0;
+            const double xq = act ? Kqb[q] : nanv;
+            // ---- strike evaluation (q-lane): j = largest index with K[j] <= xq
+            // level 1: seven independent broadcast reads of the pivots K[8m]; level 2: three dependent gathers
+            int j = 0;
 #pragma unroll
-                for (int st = 32; st >= 1; st >>= 1) if (Ksh[j + st] <= xq) j += st;
-            }
+            for (int m = 1; m < 8; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
+#pragma unroll
+            for (int st = 4; st >= 1; st >>= 1) if (Ksh[j + st] <= xq) j += st;
             const double xl = Ksh[DK - 1];
-            const int jj = j < 0 ? 0 : (j > DK - 2 ? DK - 2 : j);
+            const bool left = !(Ksh[0] <= xq);
+            const int jj = j > DK - 2 ? DK - 2 : j;
             const double x0 = Ksh[jj], x1 = Ksh[jj + 1];
             const int o0 = d_sl(jj), o1 = d_sl(jj + 1);
             double z[DT];
             if (CUB) {
-                const bool ok = j >= 0 && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
+                const bool ok = !left && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
                 const double u = xq - x0, t = u * RDX[jj], omt = 1.0 - t;
-                const double nanv = __builtin_nan("");
                 const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
                 const double w1 = t * t * (3.0 - 2.0 * t);
                 const double w2 = u * omt * omt;
                 const double w3 = u * t * (t - 1.0);
 #pragma unroll
-                for (int tt = 0; tt < DT; ++tt)
-                    z[tt] = w0 * Y[tt * D_RS + o0] + w1 * Y[tt * D_RS + o1] + w2 * S[tt * D_RS + o0] + w3 * S[tt * D_RS + o1];
+                for (int r = 0; r < DT; ++r) {
+                    z[r] = w0 * Y[r * D_RS + o0] + w1 * Y[r * D_RS + o1] + w2 * S[r * D_RS + o0] + w3 * S[r * D_RS + o1];
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the number of gathers in flight
+                }
             } else {
-                const bool left = j < 0;
                 const bool right = j >= DK - 1;
                 const bool hold = right && (METHOD == IVS_LINEAR || xq == xl);
+                const double dx = x1 - x0, rdx = refined_rcp(dx);
+                const bool dxs = div_safe(dx);
 #pragma unroll
-                for (int tt = 0; tt < DT; ++tt) {
-                    const double y0 = Y[tt * D_RS + o0], y1 = Y[tt * D_RS + o1];
-                    double r = lerp_np(xq, x0, y0, x1, y1);
-                    if (right) r = hold ? y1 : __builtin_nan("");       // jj = 62 -> y1 is the last quote
-                    if (left) r = __builtin_nan("");
-                    z[tt] = r;
+                for (int r = 0; r < DT; ++r) {
+                    const double y0 = Y[r * D_RS + o0], y1 = Y[r * D_RS + o1];
+                    double v = lerp_np_rcp(xq, x0, y0, x1, y1, dx, rdx, dxs);
+                    if (right) v = hold ? y1 : nanv;      // jj = 62 -> y1 is the last quote
+                    if (left) v = nanv;
+                    z[r] = v;
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            stamp(3);
             // ---- maturity direction (q-lane, registers)
             double* orow = outb + q;
             int tq = 0;
-            const double nanv = __builtin_nan("");
-            for (int c = 0; c < n_left; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = nanv;
+            for (int c = 0; c < tt.n_left; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = nanv;
             if (CUB) {
-                double dz[15];
-#pragma unroll
-                for (int i = 0; i < 15; ++i) dz[i] = z[i + 1] - z[i];
                 double s[DT];
                 double prev = 0.0;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
                     const double2 pq = *reinterpret_cast<const double2*>(TT + i * 4);
                     const double2 ac = *reinterpret_cast<const double2*>(TT + i * 4 + 2);
-                    const double dA = i == 0 ? dz[0] : (i == DT - 1 ? dz[DT - 3] : dz[i - 1]);
-                    const double dB = i == 0 ? dz[1] : (i == DT - 1 ? dz[DT - 2] : dz[i]);
+                    // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
+                    const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
                     prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
                     s[i] = prev;
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the table loads from piling up in registers
                 }
 #pragma unroll
-                for (int i = DT - 2; i >= 0; --i) s[i] = s[i] - TT[i * 4 + 3] * s[i + 1];
+                for (int i = DT - 2; i >= 0; --i) {
+                    s[i] = s[i] - TT[i * 4 + 3] * s[i + 1];
+                    if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+                stamp(4);
 #pragma unroll
                 for (int jv = 0; jv < DT - 1; ++jv) {
-                    const int n = __builtin_amdgcn_readfirstlane(CNT[1 + jv]);
-                    for (int c = 0; c < n; ++c, ++tq) {
-                        const double2 wa = *reinterpret_cast<const double2*>(W + tq * 4);
-                        const double2 wb = *reinterpret_cast<const double2*>(W + tq * 4 + 2);
-                        const double r = wa.x * z[jv] + wa.y * z[jv + 1] + wb.x * s[jv] + wb.y * s[jv + 1];
+                    for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+                        const double a0 = readlane_f64(tt.w0, tq), a1 = readlane_f64(tt.w1, tq);
+                        const double a2 = readlane_f64(tt.w2, tq), a3 = readlane_f64(tt.w3, tq);
+                        const double r = a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1];
                         if (act) orow[(int64_t)tq * mK] = r;
                     }
                 }
             } else {
 #pragma unroll
                 for (int jv = 0; jv < DT - 1; ++jv) {
-                    const int n = __builtin_amdgcn_readfirstlane(CNT[1 + jv]);
-                    for (int c = 0; c < n; ++c, ++tq) {
-                        const double2 wa = *reinterpret_cast<const double2*>(W + tq * 4);   // {x, T_j}
-                        const double x1t = W[tq * 4 + 2];                                     // T_{j+1}
-                        const double r = lerp_np(wa.x, wa.y, z[jv], x1t, z[jv + 1]);
+                    for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+                        const double xt = readlane_f64(tt.w0, tq), t0 = readlane_f64(tt.w1, tq);
+                        const double t1 = readlane_f64(tt.w2, tq), rdt = readlane_f64(tt.w3, tq);
+                        const double dt = t1 - t0;
+                        const double r = lerp_np_rcp(xt, t0, z[jv], t1, z[jv + 1], dt, rdt, div_safe(dt));
                         if (act) orow[(int64_t)tq * mK] = r;
                     }
                 }
             }
-            for (int c = 0; c < n_hold; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = z[DT - 1];
-            for (int c = 0; c < n_nan; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = nanv;
+            for (int c = 0; c < tt.n_hold; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = z[DT - 1];
+            for (int c = 0; c < tt.n_nan; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = nanv;
+            stamp(5);
         }
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
+        if (STAMP) acc[7] += 1;
+    }
+    if (STAMP && dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D_NSTAMP; ++i) dbg[(size_t)blockIdx.x * D_NSTAMP + i] = acc[i];
     }
 }
 
@@ -422,22 +533,42 @@ inline bool launch_surface_generic(const SurfaceParams& p, int num_cu, hipStream
 
 // Dense dispatch.  Returns 1 if dispatched (dense kernel + filtered generic redo pass), 0 if the
 // shape is not covered by a dense kernel.
-inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name) {
+inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name,
+                                unsigned long long* dbg = nullptr, int64_t* grid_out = nullptr) {
     if (p.k_off || p.nK != DK || p.nT != DT) return 0;
     if (p.k_stride != 0 && p.k_stride < DK) return 0;
     if (reinterpret_cast<uintptr_t>(p.sigma) & 15) return 0;
-    const size_t lds = dense_lds_bytes(p.mT);
-    if (lds > 64 * 1024) return 0;
+    if (p.mT > D_MAX_MT) return 0;
+    const size_t lds = dense_lds_bytes();
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu > 8 ? 8 : per_cu;
     int64_t grid = (int64_t)num_cu * per_cu;
     if (grid > p.B) grid = p.B;
+    if (grid_out) *grid_out = grid;
+    const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
+    if (dbg) {   // diagnostic build: cubic and linear, shared T only
+        if (!tsh) return 0;
+        if (p.method == IVS_CUBIC) {
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<IVS_CUBIC, true, true>));
+            hipLaunchKernelGGL((surface_dense_kernel<IVS_CUBIC, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
+        } else {
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<IVS_LINEAR, true, true>));
+            hipLaunchKernelGGL((surface_dense_kernel<IVS_LINEAR, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
+        }
+        *name = "surface_dense_kernel<stamp>";
+        return hipGetLastError() == hipSuccess ? 1 : -1;
+    }
 #define IVS_DENSE_CASE(M, NAME)                                                                            \
     case M: {                                                                                              \
         static bool attr = false;                                                                          \
-        if (!attr) { set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<M>)); attr = true; }   \
-        hipLaunchKernelGGL(surface_dense_kernel<M>, dim3((unsigned)grid), dim3(64), lds, st, p);           \
+        if (!attr) {                                                                                       \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<M, true, false>));              \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<M, false, false>));             \
+            attr = true;                                                                                   \
+        }                                                                                                  \
+        if (tsh) hipLaunchKernelGGL((surface_dense_kernel<M, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);  \
+        else hipLaunchKernelGGL((surface_dense_kernel<M, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);     \
         *name = NAME;                                                                                      \
         break;                                                                                             \
     }
