@@ -27,9 +27,11 @@ constexpr unsigned long long D_SENTINEL = REDO_SENTINEL;           // NaN payloa
 
 __device__ __forceinline__ int d_sl(int k) { return (k >> 4) * 18 + (k & 15); }
 
-__host__ __device__ inline size_t dense_lds_bytes() {
-    // Y, S planes (the strike tables AL..PSI alias the S plane); Ksh, RDX; Tsh; TT [16][4]
-    return (size_t)(2 * DT * D_RS + 64 + 64 + 16 + 64) * 8;
+constexpr int D_WLDS_MAX_MT = 16;                // query-row weights live in LDS up to this many rows
+__host__ __device__ inline size_t dense_lds_bytes(int mT) {
+    // Y, S planes (the strike tables AL..PSI and the T-phase scratch alias them); Ksh, RDX; TT [16][4];
+    // W [16][4] when mT <= 16 (exactly 20480 B = 8 workgroups per CU), else weights stay in registers
+    return (size_t)(2 * DT * D_RS + 64 + 64 + 64 + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
 }
 
 // codes of a query row in the maturity direction
@@ -89,27 +91,42 @@ __device__ __forceinline__ double lerp_np_rcp(double xq, double x0, double y0, d
     return r;
 }
 
+// Branch-free fast path of the same formula: `slow` is raised whenever the value must be recomputed by
+// lerp_np() (operand outside the safe division range, or a NaN that needs np.interp's fallback rules).
+__device__ __forceinline__ double lerp_fast(double xq, double x0, double y0, double y1, double dx, double rdx,
+                                            bool& slow) {
+#pragma clang fp contract(off)
+    const double a = y1 - y0;
+    const double q = a * rdx;
+    const double rem = __builtin_fma(-q, dx, a);
+    const double slope = __builtin_fma(rem, rdx, q);
+    const double res = slope * (xq - x0) + y0;
+    const double aa = __builtin_fabs(a);
+    slow |= !((a == 0.0) || (aa >= 0x1p-500 && aa <= 0x1p500)) || __builtin_isnan(res);
+    return (x0 == xq) ? y0 : res;
+}
+
 // Inclusive scan over lanes 0..N-1 (N = 16 or 64) of 2x2 matrix products P_i <- P_i * P_{i-1} * ... * P_0.
 template <int N>
 __device__ __forceinline__ void scan_mat2(double& p00, double& p01, double& p10, double& p11, int lane) {
-#define IVS_SCAN_STEP(CTRL, MASK, COND)                                                        \
+    // lanes without a valid source (row start, rows masked off) receive the IDENTITY through the DPP
+    // `old` operand, so every lane multiplies unconditionally: no compare/select per step
+#define IVS_SCAN_STEP(CTRL, MASK)                                                              \
     {                                                                                          \
-        const double e = dpp_f64<CTRL, MASK>(p00, p00), f = dpp_f64<CTRL, MASK>(p01, p01);     \
-        const double g = dpp_f64<CTRL, MASK>(p10, p10), h = dpp_f64<CTRL, MASK>(p11, p11);     \
-        if (COND) {                                                                            \
-            const double n00 = p00 * e + p01 * g, n01 = p00 * f + p01 * h;                     \
-            const double n10 = p10 * e + p11 * g, n11 = p10 * f + p11 * h;                     \
-            p00 = n00; p01 = n01; p10 = n10; p11 = n11;                                        \
-        }                                                                                      \
+        const double e = dpp_f64<CTRL, MASK>(1.0, p00), f = dpp_f64<CTRL, MASK>(0.0, p01);     \
+        const double g = dpp_f64<CTRL, MASK>(0.0, p10), h = dpp_f64<CTRL, MASK>(1.0, p11);     \
+        const double n00 = p00 * e + p01 * g, n01 = p00 * f + p01 * h;                         \
+        const double n10 = p10 * e + p11 * g, n11 = p10 * f + p11 * h;                         \
+        p00 = n00; p01 = n01; p10 = n10; p11 = n11;                                            \
     }
-    const int r = lane & 15;
-    IVS_SCAN_STEP(DPP_ROW_SHR(1), 0xF, r >= 1)
-    IVS_SCAN_STEP(DPP_ROW_SHR(2), 0xF, r >= 2)
-    IVS_SCAN_STEP(DPP_ROW_SHR(4), 0xF, r >= 4)
-    IVS_SCAN_STEP(DPP_ROW_SHR(8), 0xF, r >= 8)
+    (void)lane;
+    IVS_SCAN_STEP(DPP_ROW_SHR(1), 0xF)
+    IVS_SCAN_STEP(DPP_ROW_SHR(2), 0xF)
+    IVS_SCAN_STEP(DPP_ROW_SHR(4), 0xF)
+    IVS_SCAN_STEP(DPP_ROW_SHR(8), 0xF)
     if (N > 16) {
-        IVS_SCAN_STEP(DPP_ROW_BCAST15, 0xA, (lane & 16) != 0)     // rows 1,3 <- lane 15 of rows 0,2
-        IVS_SCAN_STEP(DPP_ROW_BCAST31, 0xC, lane >= 32)           // rows 2,3 <- lane 31
+        IVS_SCAN_STEP(DPP_ROW_BCAST15, 0xA)     // rows 1,3 <- lane 15 of rows 0,2
+        IVS_SCAN_STEP(DPP_ROW_BCAST31, 0xC)     // rows 2,3 <- lane 31
     }
 #undef IVS_SCAN_STEP
 }
@@ -170,21 +187,19 @@ __device__ __forceinline__ void factor_tables(const double* X, int lane, double&
 
 // segmented inclusive prefix / suffix products within aligned rows of 16 lanes
 __device__ __forceinline__ double seg16_prefix_prod(double v, int lane) {
-    const int r = lane & 15;
-    double o;
-    o = dpp_f64<DPP_ROW_SHR(1)>(1.0, v); if (r >= 1) v *= o;
-    o = dpp_f64<DPP_ROW_SHR(2)>(1.0, v); if (r >= 2) v *= o;
-    o = dpp_f64<DPP_ROW_SHR(4)>(1.0, v); if (r >= 4) v *= o;
-    o = dpp_f64<DPP_ROW_SHR(8)>(1.0, v); if (r >= 8) v *= o;
+    (void)lane;                                   // out-of-row sources read as 1.0 (DPP `old`)
+    v *= dpp_f64<DPP_ROW_SHR(1)>(1.0, v);
+    v *= dpp_f64<DPP_ROW_SHR(2)>(1.0, v);
+    v *= dpp_f64<DPP_ROW_SHR(4)>(1.0, v);
+    v *= dpp_f64<DPP_ROW_SHR(8)>(1.0, v);
     return v;
 }
 __device__ __forceinline__ double seg16_suffix_prod(double v, int lane) {
-    const int r = lane & 15;
-    double o;
-    o = dpp_f64<DPP_ROW_SHL(1)>(1.0, v); if (r + 1 < 16) v *= o;
-    o = dpp_f64<DPP_ROW_SHL(2)>(1.0, v); if (r + 2 < 16) v *= o;
-    o = dpp_f64<DPP_ROW_SHL(4)>(1.0, v); if (r + 4 < 16) v *= o;
-    o = dpp_f64<DPP_ROW_SHL(8)>(1.0, v); if (r + 8 < 16) v *= o;
+    (void)lane;
+    v *= dpp_f64<DPP_ROW_SHL(1)>(1.0, v);
+    v *= dpp_f64<DPP_ROW_SHL(2)>(1.0, v);
+    v *= dpp_f64<DPP_ROW_SHL(4)>(1.0, v);
+    v *= dpp_f64<DPP_ROW_SHL(8)>(1.0, v);
     return v;
 }
 
@@ -194,24 +209,27 @@ __device__ __forceinline__ double seg16_suffix_prod(double v, int lane) {
 template <bool STAMPED, class StampFn>
 __device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, const double* Ksh, double* RDX,
                                                     int lane, StampFn&& stamp) {
-    double* AL = S;                    // strike tables alias the S plane: dead before S is written
-    double* CP = S + 64;
-    double* PP = S + 128;
-    double* QQ = S + 192;
-    double* PI = S + 256;
-    double* PSI = S + 320;
+    // strike tables alias the S plane (dead before S is written); knot k sits at d_sl(k) so that the four
+    // segment-broadcast reads of a sweep step hit four different bank groups
+    double* AL = S;
+    double* CP = S + 72;
+    double* PP = S + 144;
+    double* QQ = S + 216;
+    double* PI = S + 288;
+    double* PSI = S + 360;
     const int rs_t = lane >> 2, rs_seg = lane & 3;
     // ---- K-phase (k-lane)
     double al, cp, pp, qq, rdx;
     factor_tables<DK>(Ksh, lane, al, cp, pp, qq, rdx);
-    AL[lane] = al; CP[lane] = cp; PP[lane] = pp; QQ[lane] = qq; RDX[lane] = rdx;
-    PI[lane] = seg16_prefix_prod(-al, lane);       // prod_{seg start..i} (-AL)
-    PSI[lane] = seg16_suffix_prod(-cp, lane);      // prod_{i..seg end} (-CP)
+    const int kl = d_sl(lane);
+    AL[kl] = al; CP[kl] = cp; PP[kl] = pp; QQ[kl] = qq; RDX[lane] = rdx;
+    PI[kl] = seg16_prefix_prod(-al, lane);         // prod_{seg start..i} (-AL)
+    PSI[kl] = seg16_suffix_prod(-cp, lane);        // prod_{i..seg end} (-CP)
     __syncthreads();
     if (STAMPED) stamp(1);
     // ---- strike sweeps (rs-lane): row rs_t, knots rs_seg*16 .. +15
     const double* yrow = Y + rs_t * D_RS + rs_seg * 18;
-    const int kb = rs_seg * 16;
+    const int kb = rs_seg * 16, kp = rs_seg * 18;   // first knot of the segment / its padded table index
     double y[18];                                  // y[m+1] = y_{kb+m}, m = -1..16
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -228,13 +246,13 @@ __device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, 
         double dA = y[m + 1] - y[m], dB = y[m + 2] - y[m + 1];         // (dy_{i-1}, dy_i)
         if (m == 0) { const double e = y[3] - y[2]; dA = rs_seg == 0 ? dB : dA; dB = rs_seg == 0 ? e : dB; }
         if (m == 15) { const double e = y[15] - y[14]; dB = rs_seg == 3 ? dA : dB; dA = rs_seg == 3 ? e : dA; }
-        const double r = PP[kb + m] * dA + QQ[kb + m] * dB;
-        prev = r - AL[kb + m] * prev;
+        const double r = PP[kp + m] * dA + QQ[kp + m] * dB;
+        prev = r - AL[kp + m] * prev;
         d[m] = prev;
         if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     // carry across the 4 segments of the row (lanes 4t..4t+3 sit in one DPP row)
-    const double pie = PI[kb + 15];
+    const double pie = PI[kp + 15];
     double din = 0.0, tot = d[15];
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
@@ -244,12 +262,12 @@ __device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, 
     double nxt = 0.0;
 #pragma unroll
     for (int m = 15; m >= 0; --m) {
-        const double dp = d[m] + PI[kb + m] * din;
-        nxt = dp - CP[kb + m] * nxt;
+        const double dp = d[m] + PI[kp + m] * din;
+        nxt = dp - CP[kp + m] * nxt;
         d[m] = nxt;                                // local backward solution
         if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
-    const double psb = PSI[kb];
+    const double psb = PSI[kp];
     double sin_ = 0.0;
     tot = d[0];
 #pragma unroll
@@ -258,7 +276,7 @@ __device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, 
         if (rs_seg == j) { sin_ = v; tot = d[0] + psb * sin_; }
     }
 #pragma unroll
-    for (int m = 0; m < 16; ++m) d[m] = d[m] + PSI[kb + m] * sin_;
+    for (int m = 0; m < 16; ++m) d[m] = d[m] + PSI[kp + m] * sin_;
     __syncthreads();                               // all table reads done: the S plane may be overwritten
     double* srow = S + rs_t * D_RS + rs_seg * 18;
 #pragma unroll
@@ -280,7 +298,7 @@ struct TqTables {
     __device__ __forceinline__ int n_iv(int j) const { return (int)(((j < 8 ? iv_lo : iv_hi) >> (8 * (j & 7))) & 0xffull); }
 };
 
-template <int METHOD, bool TSHARED, bool STAMP = false>
+template <int METHOD, bool TSHARED, bool WLDS, bool STAMP = false>
 __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, unsigned long long* dbg = nullptr) {
     constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
     unsigned long long acc[D_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -302,8 +320,10 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
     double* S = Y + DT * D_RS;
     double* Ksh = S + DT * D_RS;
     double* RDX = Ksh + 64;
-    double* Tsh = RDX + 64;            // 16
-    double* TT = Tsh + 16;             // [16][4] = {PP, QQ, AL, CP} of the maturity system
+    double* TT = RDX + 64;             // [16][4] = {PP, QQ, AL, CP} of the maturity system
+    double* W = TT + 64;               // [16][4] query-row weights (only when mT <= 16)
+    double* Tsh = TSHARED ? Y : S;     // T-phase scratch: the plane that is free at the time it runs
+    constexpr bool w_lds = WLDS;       // host guarantees mT <= D_WLDS_MAX_MT when set
 
     constexpr bool t_shared = TSHARED;   // T and Tq shared by the whole batch: T-phase hoisted out of the loop
     const double nanv = __builtin_nan("");
@@ -347,6 +367,10 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         } else {
             tt.w0 = x; tt.w1 = x0; tt.w2 = x1; tt.w3 = refined_rcp(x1 - x0);
         }
+        if (w_lds && act) {
+            *reinterpret_cast<double2*>(W + tq * 4) = double2{tt.w0, tt.w1};
+            *reinterpret_cast<double2*>(W + tq * 4 + 2) = double2{tt.w2, tt.w3};
+        }
         tt.n_left = __popcll(__ballot(act && code == TQ_LEFT));
         tt.n_hold = __popcll(__ballot(act && code == TQ_HOLD));
         tt.n_nan = __popcll(__ballot(act && code == TQ_NAN));
@@ -373,6 +397,17 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         for (int i = 0; i < 8; ++i) pre[i] = s2[i * 64 + lane];
         pre_k = p.K[b * p.k_stride + lane];
     };
+    // query strikes of the first 4 column blocks live in registers: loaded once when the grid is shared,
+    // else per surface BEFORE the prefetch is issued (vmcnt retires in order: a load issued behind the
+    // prefetch would make the evaluation wait for the whole next surface)
+    constexpr int XQ_REG = 4;
+    double xq_reg[XQ_REG];
+    auto load_xq = [&](const double* Kqb) {
+#pragma unroll
+        for (int i = 0; i < XQ_REG; ++i) xq_reg[i] = (i * 64 + lane < mK) ? Kqb[i * 64 + lane] : nanv;
+    };
+    const bool kq_shared = p.kq_stride == 0;
+    if (kq_shared) load_xq(p.Kq);
     int64_t b = blockIdx.x;
     if (b < p.B) prefetch(b);
 
@@ -403,15 +438,19 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
             stamp(2);
         }
 
+        const double* Kqb = p.Kq + b * p.kq_stride;
+        if (!kq_shared) load_xq(Kqb);
         {
             const int64_t bn = b + gridDim.x;
             if (bn < p.B) prefetch(bn);                    // next surface's loads fly during evaluation + maturity pass
         }
-        const double* Kqb = p.Kq + b * p.kq_stride;
-        for (int q0 = 0; q0 < mK; q0 += 64) {
+#pragma unroll 1
+        for (int q0 = 0, qb = 0; q0 < mK; q0 += 64, ++qb) {
             const int q = q0 + lane;
             const bool act = q < mK;
-            const double xq = act ? Kqb[q] : nanv;
+            double xq;
+            if (qb < XQ_REG) xq = qb == 0 ? xq_reg[0] : (qb == 1 ? xq_reg[1] : (qb == 2 ? xq_reg[2] : xq_reg[3]));
+            else xq = act ? Kqb[q] : nanv;
             // ---- strike evaluation (q-lane): j = largest index with K[j] <= xq
             // level 1: seven independent broadcast reads of the pivots K[8m]; level 2: three dependent gathers
             int j = 0;
@@ -432,74 +471,133 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
                 const double w1 = t * t * (3.0 - 2.0 * t);
                 const double w2 = u * omt * omt;
                 const double w3 = u * t * (t - 1.0);
+                // software pipeline: the four gathers of row r+3 are issued before row r is combined,
+                // so ~12 LDS reads stay in flight (lgkmcnt holds 15) instead of waiting row by row
+                constexpr int LA = 3;
+                double g0[4], g1[4], g2[4], g3[4];
+#pragma unroll
+                for (int r = 0; r < LA; ++r) {
+                    g0[r] = Y[r * D_RS + o0]; g1[r] = Y[r * D_RS + o1]; g2[r] = S[r * D_RS + o0]; g3[r] = S[r * D_RS + o1];
+                }
 #pragma unroll
                 for (int r = 0; r < DT; ++r) {
-                    z[r] = w0 * Y[r * D_RS + o0] + w1 * Y[r * D_RS + o1] + w2 * S[r * D_RS + o0] + w3 * S[r * D_RS + o1];
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the number of gathers in flight
+                    if (r + LA < DT) {
+                        const int n = r + LA;
+                        g0[n & 3] = Y[n * D_RS + o0]; g1[n & 3] = Y[n * D_RS + o1];
+                        g2[n & 3] = S[n * D_RS + o0]; g3[n & 3] = S[n * D_RS + o1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    z[r] = w0 * g0[r & 3] + w1 * g1[r & 3] + w2 * g2[r & 3] + w3 * g3[r & 3];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 const bool right = j >= DK - 1;
                 const bool hold = right && (METHOD == IVS_LINEAR || xq == xl);
                 const double dx = x1 - x0, rdx = refined_rcp(dx);
-                const bool dxs = div_safe(dx);
+                bool slow = !div_safe(dx);
+                constexpr int LA = 6;                     // 12 gathers in flight
+                double g0[8], g1[8];
+#pragma unroll
+                for (int r = 0; r < LA; ++r) { g0[r] = Y[r * D_RS + o0]; g1[r] = Y[r * D_RS + o1]; }
 #pragma unroll
                 for (int r = 0; r < DT; ++r) {
-                    const double y0 = Y[r * D_RS + o0], y1 = Y[r * D_RS + o1];
-                    double v = lerp_np_rcp(xq, x0, y0, x1, y1, dx, rdx, dxs);
+                    if (r + LA < DT) { const int n = r + LA; g0[n & 7] = Y[n * D_RS + o0]; g1[n & 7] = Y[n * D_RS + o1]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double y0 = g0[r & 7], y1 = g1[r & 7];
+                    double v = lerp_fast(xq, x0, y0, y1, dx, rdx, slow);
                     if (right) v = hold ? y1 : nanv;      // jj = 62 -> y1 is the last quote
                     if (left) v = nanv;
                     z[r] = v;
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (__builtin_expect(__ballot(slow && !right && !left) != 0ull, 0)) {   // rare: full IEEE path
+                    if (slow && !right && !left) {
+#pragma unroll
+                        for (int r = 0; r < DT; ++r) z[r] = lerp_np(xq, x0, Y[r * D_RS + o0], x1, Y[r * D_RS + o1]);
+                    }
                 }
             }
             stamp(3);
-            // ---- maturity direction (q-lane, registers)
-            double* orow = outb + q;
+            // ---- maturity direction (q-lane, registers).  Row pointers are wave-uniform (scalar base),
+            // the lane contributes only its 32-bit column offset.
             int tq = 0;
-            for (int c = 0; c < tt.n_left; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = nanv;
+            auto put = [&](int row, double v) {
+                double* rp = outb + (int64_t)row * mK + q0;           // uniform
+                if (act) rp[lane] = v;
+            };
+            for (int c = 0; c < tt.n_left; ++c, ++tq) put(tq, nanv);
+            // weights of row tq: LDS broadcast (prefetched one row ahead) when mT <= 16, else readlane
+            const double2* W2 = reinterpret_cast<const double2*>(W);
+            double2 wa_n = double2{0.0, 0.0}, wb_n = double2{0.0, 0.0};
+            if (w_lds) { const int t0 = tq < mT ? tq : 0; wa_n = W2[2 * t0]; wb_n = W2[2 * t0 + 1]; }
+            auto weights = [&](int row, double& a0, double& a1, double& a2, double& a3) {
+                if (w_lds) {
+                    a0 = wa_n.x; a1 = wa_n.y; a2 = wb_n.x; a3 = wb_n.y;
+                    const int nx = row + 1 < mT ? row + 1 : row;      // prefetch the next row's weights
+                    wa_n = W2[2 * nx]; wb_n = W2[2 * nx + 1];
+                } else {
+                    a0 = readlane_f64(tt.w0, row); a1 = readlane_f64(tt.w1, row);
+                    a2 = readlane_f64(tt.w2, row); a3 = readlane_f64(tt.w3, row);
+                }
+            };
             if (CUB) {
                 double s[DT];
                 double prev = 0.0;
+                {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
+                    constexpr int LA = 4;
+                    double2 tpq[4], tac[4];
 #pragma unroll
-                for (int i = 0; i < DT; ++i) {
-                    const double2 pq = *reinterpret_cast<const double2*>(TT + i * 4);
-                    const double2 ac = *reinterpret_cast<const double2*>(TT + i * 4 + 2);
-                    // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
-                    const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
-                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
-                    prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
-                    s[i] = prev;
-                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the table loads from piling up in registers
-                }
+                    for (int i = 0; i < LA; ++i) {
+                        tpq[i] = *reinterpret_cast<const double2*>(TT + i * 4);
+                        tac[i] = *reinterpret_cast<const double2*>(TT + i * 4 + 2);
+                    }
+                    double cpv[DT];                                // CP_i, kept for the backward sweep
 #pragma unroll
-                for (int i = DT - 2; i >= 0; --i) {
-                    s[i] = s[i] - TT[i * 4 + 3] * s[i + 1];
-                    if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < DT; ++i) {
+                        const double2 pq = tpq[i & 3], ac = tac[i & 3];
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i + LA < DT) {
+                            tpq[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4);
+                            tac[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4 + 2);
+                        }
+                        // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
+                        const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                        const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                        prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
+                        s[i] = prev;
+                        cpv[i] = ac.y;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = DT - 2; i >= 0; --i) s[i] = s[i] - cpv[i] * s[i + 1];
                 }
                 stamp(4);
 #pragma unroll
                 for (int jv = 0; jv < DT - 1; ++jv) {
                     for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
-                        const double a0 = readlane_f64(tt.w0, tq), a1 = readlane_f64(tt.w1, tq);
-                        const double a2 = readlane_f64(tt.w2, tq), a3 = readlane_f64(tt.w3, tq);
-                        const double r = a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1];
-                        if (act) orow[(int64_t)tq * mK] = r;
+                        double a0, a1, a2, a3;
+                        weights(tq, a0, a1, a2, a3);
+                        put(tq, a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1]);
                     }
                 }
             } else {
 #pragma unroll
                 for (int jv = 0; jv < DT - 1; ++jv) {
                     for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
-                        const double xt = readlane_f64(tt.w0, tq), t0 = readlane_f64(tt.w1, tq);
-                        const double t1 = readlane_f64(tt.w2, tq), rdt = readlane_f64(tt.w3, tq);
+                        double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
+                        weights(tq, xt, t0, t1, rdt);
                         const double dt = t1 - t0;
-                        const double r = lerp_np_rcp(xt, t0, z[jv], t1, z[jv + 1], dt, rdt, div_safe(dt));
-                        if (act) orow[(int64_t)tq * mK] = r;
+                        bool slow = !div_safe(dt);
+                        double r = lerp_fast(xt, t0, z[jv], z[jv + 1], dt, rdt, slow);
+                        if (__builtin_expect(__ballot(slow) != 0ull, 0)) {
+                            if (slow) r = lerp_np(xt, t0, z[jv], t1, z[jv + 1]);
+                        }
+                        put(tq, r);
                     }
                 }
             }
-            for (int c = 0; c < tt.n_hold; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = z[DT - 1];
-            for (int c = 0; c < tt.n_nan; ++c, ++tq) if (act) orow[(int64_t)tq * mK] = nanv;
+            for (int c = 0; c < tt.n_hold; ++c, ++tq) put(tq, z[DT - 1]);
+            for (int c = 0; c < tt.n_nan; ++c, ++tq) put(tq, nanv);
             stamp(5);
         }
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
@@ -539,7 +637,7 @@ inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t 
     if (p.k_stride != 0 && p.k_stride < DK) return 0;
     if (reinterpret_cast<uintptr_t>(p.sigma) & 15) return 0;
     if (p.mT > D_MAX_MT) return 0;
-    const size_t lds = dense_lds_bytes();
+    const size_t lds = dense_lds_bytes(p.mT);
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu > 8 ? 8 : per_cu;
@@ -547,28 +645,25 @@ inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t 
     if (grid > p.B) grid = p.B;
     if (grid_out) *grid_out = grid;
     const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
+    const bool wl = p.mT <= D_WLDS_MAX_MT;
     if (dbg) {   // diagnostic build: cubic and linear, shared T only
         if (!tsh) return 0;
         if (p.method == IVS_CUBIC) {
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<IVS_CUBIC, true, true>));
-            hipLaunchKernelGGL((surface_dense_kernel<IVS_CUBIC, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
+            if (wl) hipLaunchKernelGGL((surface_dense_kernel<IVS_CUBIC, true, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
+            else hipLaunchKernelGGL((surface_dense_kernel<IVS_CUBIC, true, false, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
         } else {
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<IVS_LINEAR, true, true>));
-            hipLaunchKernelGGL((surface_dense_kernel<IVS_LINEAR, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
+            if (wl) hipLaunchKernelGGL((surface_dense_kernel<IVS_LINEAR, true, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
+            else hipLaunchKernelGGL((surface_dense_kernel<IVS_LINEAR, true, false, true>), dim3((unsigned)grid), dim3(64), lds, st, p, dbg);
         }
         *name = "surface_dense_kernel<stamp>";
         return hipGetLastError() == hipSuccess ? 1 : -1;
     }
 #define IVS_DENSE_CASE(M, NAME)                                                                            \
     case M: {                                                                                              \
-        static bool attr = false;                                                                          \
-        if (!attr) {                                                                                       \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<M, true, false>));              \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_kernel<M, false, false>));             \
-            attr = true;                                                                                   \
-        }                                                                                                  \
-        if (tsh) hipLaunchKernelGGL((surface_dense_kernel<M, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);  \
-        else hipLaunchKernelGGL((surface_dense_kernel<M, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);     \
+        if (tsh && wl) hipLaunchKernelGGL((surface_dense_kernel<M, true, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);        \
+        else if (tsh) hipLaunchKernelGGL((surface_dense_kernel<M, true, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);        \
+        else if (wl) hipLaunchKernelGGL((surface_dense_kernel<M, false, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);         \
+        else hipLaunchKernelGGL((surface_dense_kernel<M, false, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);                \
         *name = NAME;                                                                                      \
         break;                                                                                             \
     }
