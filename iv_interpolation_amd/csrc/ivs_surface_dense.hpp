@@ -624,7 +624,8 @@ inline bool launch_surface_generic(const SurfaceParams& p, int num_cu, hipStream
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
     int64_t grid = (int64_t)num_cu * per_cu * 2;
-    if (grid > p.B) grid = p.B;
+    const int64_t work = FILTER ? (p.B + 63) / 64 : p.B;
+    if (grid > work) grid = work;
     hipLaunchKernelGGL(surface_generic_kernel<FILTER>, dim3((unsigned)grid), dim3(64), lds, st, p);
     return true;
 }

@@ -68,7 +68,21 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
     uint8_t* ctidx = reinterpret_cast<uint8_t*>(cs + (size_t)nT * 64);
     int* nrow = reinterpret_cast<int*>(ctidx + (size_t)nT * 64);
 
-    for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
+    // FILTER: a wave inspects 64 surfaces per load (lane i reads the tag of surface base+i) and only walks the
+    // tagged ones, so the redo pass costs microseconds when nothing was tagged.
+    const int64_t n_outer = FILTER ? (p.B + 63) / 64 : p.B;
+    for (int64_t ob = blockIdx.x; ob < n_outer; ob += gridDim.x) {
+      unsigned long long todo = 1ull;
+      if (FILTER) {
+          const int64_t bi = ob * 64 + lane;
+          const bool tagged = bi < p.B &&
+              reinterpret_cast<const unsigned long long*>(p.out + bi * (int64_t)p.mT * p.mK)[0] == REDO_SENTINEL;
+          todo = __ballot(tagged);
+      }
+      while (todo) {
+        const int bit = FILTER ? __builtin_ctzll(todo) : 0;
+        todo &= todo - 1;
+        const int64_t b = FILTER ? ob * 64 + bit : ob;
         int64_t koff; int nKb;
         if (p.k_off) { koff = p.k_off[b]; nKb = (int)(p.k_off[b + 1] - koff); }
         else { koff = b * p.k_stride; nKb = nKmax; }
@@ -79,7 +93,6 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
         const double* Tqb = p.Tq + b * p.tq_stride;
         double* outb = p.out + b * (int64_t)p.mT * p.mK;
         int st = 0;
-        if (FILTER && reinterpret_cast<const unsigned long long*>(outb)[0] != REDO_SENTINEL) continue;   // wave-uniform
 
         __syncthreads();   // previous surface's readers are done with LDS
         for (int k = lane; k < nKb; k += 64) Ksh[k] = Kb[k];
@@ -157,6 +170,7 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
             unsigned long long any = __ballot(st != 0);
             if (lane == 0) p.status[b] = any ? IVS_ST_TOO_FEW_KNOTS : IVS_ST_OK;
         }
+      }
     }
 }
 
