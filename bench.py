@@ -110,12 +110,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local)
+    # one process per GPU; IVS_DIST_BACKEND=gloo + fewer devices than ranks is only for rehearsing the N>1 code
+    # path on a 1-GPU box (ranks then share cuda:0)
+    backend = os.environ.get("IVS_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local if backend == "nccl" else local % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     nK, nT, mK, mT, ragged, desc = WORKLOADS[a.workload]
     B = a.batch
@@ -157,7 +165,7 @@ def main():
     wall = time.perf_counter() - t0
     kern_ms = [s.elapsed_time(e) for s, e in ev]
     if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
     assert int(status.max()) == 0
