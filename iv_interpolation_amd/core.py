@@ -56,8 +56,8 @@ class HipBackend:
 
 
 class _Prepared:
-    __slots__ = ("df", "timeline", "rows_on", "pos", "rowlat", "M", "chan_src", "chan_needs", "fill_cols",
-                 "fill_valid", "other_cols")
+    __slots__ = ("df", "timeline", "pos", "rowlat", "M", "chan_src", "chan_needs", "fill_cols",
+                 "fill_valid", "src_np", "int_dtype")
 
 
 class IVInterpolator:
@@ -171,7 +171,15 @@ class IVInterpolator:
             cnt = np.maximum(np.bincount(lat, minlength=m0), 1)
             rowlat = np.repeat(np.arange(m0), cnt)
         p = _Prepared()
-        p.df, p.timeline, p.rows_on, p.pos, p.rowlat, p.M = df, timeline, rows_on, pos, rowlat, M
+        p.df, p.timeline, p.pos, p.rowlat, p.M = df, timeline, pos, rowlat, M
+        # source columns as NumPy arrays restricted to the rows that landed on the lattice
+        p.src_np, p.int_dtype = {}, {}
+        for c in df.columns:
+            if c == "date":
+                continue
+            v = df[c].to_numpy()
+            p.int_dtype[c] = v.dtype if v.dtype.kind in "iub" else None
+            p.src_np[c] = v[rows_on]
         p.chan_src, p.chan_needs = [], []
         for c in NUMERIC_COLS:                                           # core.py:58-61
             v = df[c].to_numpy(dtype=np.float64, na_value=np.nan)[rows_on]
@@ -179,23 +187,21 @@ class IVInterpolator:
             nn = int(np.isnan(v).sum()) + (M - q)                        # NaNs of the merged column
             p.chan_needs.append(0 < nn < M)                              # pandas: all-NaN / no-NaN columns are left alone
         p.fill_cols = [c for c in FILL_COLS if c in df.columns]          # core.py:64-68
-        p.fill_valid = [df[c].notna().to_numpy()[rows_on].astype(np.uint8) for c in p.fill_cols]
-        p.other_cols = [c for c in df.columns if c != "date" and c not in NUMERIC_COLS and c not in FILL_COLS]
+        p.fill_valid = [(~pd.isna(p.src_np[c])).astype(np.uint8) for c in p.fill_cols]
         return p
 
     def _assemble(self, p: _Prepared, out, status, fill_idx, fill_missing) -> Optional[pd.DataFrame]:
         df, M = p.df, p.M
+        q = len(p.pos)
         for c in range(len(NUMERIC_COLS)):
             if p.chan_needs[c] and status[c] != ST_OK:
                 # scipy raises inside Series.interpolate (too few knots) -> core.py:83-85
                 raise ValueError("The number of derivatives at boundaries does not match: "
                                  f"too few valid knots in '{NUMERIC_COLS[c]}' for method '{self.method}'")
-        src = df.iloc[p.rows_on].reset_index(drop=True)
-        raw_idx = np.full(M, -1, np.int64)
-        raw_idx[p.pos] = np.arange(len(p.pos))
-        cols = {}
+        nothing_missing = M == q
+        raw_idx = None
         dates = p.timeline if p.rowlat is None else p.timeline[p.rowlat]
-        cols["date"] = pd.Series(dates).reset_index(drop=True)
+        cols = {"date": dates}
         for name in df.columns:
             if name == "date":
                 continue
@@ -205,21 +211,30 @@ class IVInterpolator:
                 merged[p.pos] = p.chan_src[ci]
                 if p.chan_needs[ci]:
                     merged = np.where(np.isnan(merged), out[ci], merged)
-                s = pd.Series(merged)
-                if M == len(p.pos) and df[name].dtype.kind in "iu":      # nothing missing: int column stays int
-                    s = s.astype(df[name].dtype)
-                cols[name] = s
+                if nothing_missing and p.int_dtype[name] is not None:    # nothing missing: int column stays int
+                    merged = merged.astype(p.int_dtype[name])
+                elif df[name].dtype == object:                           # object-typed numeric column keeps its dtype
+                    merged = merged.astype(object)
+                cols[name] = merged
             elif name in p.fill_cols:
                 fi = p.fill_cols.index(name)
-                gi = np.where(fill_missing[fi], -1, fill_idx[fi])
-                cols[name] = _gather(src[name], gi, M == len(p.pos))
+                cols[name] = _gather(p.src_np[name], np.where(fill_missing[fi], -1, fill_idx[fi]), p.int_dtype[name],
+                                     nothing_missing)
             else:
-                cols[name] = _gather(src[name], raw_idx, M == len(p.pos))
-        merged = pd.DataFrame(cols, columns=["date"] + [c for c in df.columns if c != "date"])
-        merged["is_interpolated"] = merged["symbol"].isna().to_numpy()   # core.py:71 (after ffill -> always False)
-        keep = np.ones(M, bool)
-        for c in REQUIRED:                                               # core.py:74
-            keep &= merged[c].notna().to_numpy()
+                if raw_idx is None:
+                    raw_idx = np.full(M, -1, np.int64)
+                    raw_idx[p.pos] = np.arange(q)
+                cols[name] = _gather(p.src_np[name], raw_idx, p.int_dtype[name], nothing_missing)
+        sym = cols["symbol"]
+        sym_na = pd.isna(sym)
+        keep = ~sym_na                                                    # core.py:74
+        for c in REQUIRED[1:]:
+            keep &= ~pd.isna(cols[c])
+        cols["is_interpolated"] = sym_na                                  # core.py:71 (after ffill -> always False)
+        order = ["date"] + [c for c in df.columns if c != "date"]
+        if "is_interpolated" not in order:
+            order.append("is_interpolated")
+        merged = pd.DataFrame({c: cols[c] for c in order}, copy=False)
         if not keep.all():
             merged = merged[keep]
         if merged.empty:                                                 # core.py:76-78
@@ -229,12 +244,30 @@ class IVInterpolator:
         return merged
 
 
-def _gather(col: pd.Series, idx: np.ndarray, nothing_missing: bool) -> pd.Series:
-    """col[idx] with -1 -> missing, dtype-promoting exactly like a left merge (int -> float, object -> NaN)."""
-    if nothing_missing and (idx >= 0).all():
-        return col.take(idx).reset_index(drop=True)
-    if (idx >= 0).all() and col.dtype.kind in "iub":
-        # the merge introduced missing rows elsewhere in the frame -> pandas already promoted this column
-        return col.astype(np.float64).take(idx).reset_index(drop=True)
-    r = col.reindex(idx)          # label -1 is absent from the RangeIndex -> NaN / None / NaT
-    return r.reset_index(drop=True)
+def _gather(values: np.ndarray, idx: np.ndarray, int_dtype, nothing_missing: bool) -> np.ndarray:
+    """values[idx] with -1 -> missing, dtype-promoting exactly like the reference's left merge + ffill
+    (int/bool -> float64 as soon as the merge introduced a missing row, object -> NaN, datetime -> NaT)."""
+    miss = idx < 0
+    any_miss = bool(miss.any())
+    safe = np.where(miss, 0, idx) if any_miss else idx
+    if int_dtype is not None:
+        if nothing_missing and not any_miss:
+            return values[safe]
+        if int_dtype.kind == "b":                                        # bool + NaN -> object in pandas
+            r = values[safe].astype(object)
+            if any_miss:
+                r[miss] = np.nan
+            return r
+        r = values[safe].astype(np.float64)
+        if any_miss:
+            r[miss] = np.nan
+        return r
+    r = values[safe]
+    if any_miss:
+        if r.dtype.kind == "f":
+            r = r.copy(); r[miss] = np.nan
+        elif r.dtype.kind in "mM":
+            r = r.copy(); r[miss] = np.datetime64("NaT") if r.dtype.kind == "M" else np.timedelta64("NaT")
+        else:
+            r = r.astype(object); r[miss] = np.nan
+    return r

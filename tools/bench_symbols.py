@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""The reference's own shape: S option symbols, 64 hourly rows each -> 3781 one-minute
+rows, three interpolated channels + nine forward-filled columns.  Reports
+  (1) device kernels only (packed columns resident in HBM): symbols/s, output rows/s, GB/s vs HBM peak
+  (2) end to end through IVInterpolator.interpolate_batch (DataFrames in, DataFrames out; includes packing, PCIe, pandas)
+  (3) the CPU restatement of interpolate_symbol (oracle/ref_symbol.py, one core) on a bounded sample."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import torch
+from iv_interpolation_amd import IVInterpolator, engine
+from iv_interpolation_amd.frame_store import synthetic_symbol
+
+ap = argparse.ArgumentParser(); ap.add_argument("--symbols", type=int, default=4096); ap.add_argument("--hours", type=int, default=64)
+ap.add_argument("--method", default="linear"); ap.add_argument("--e2e", type=int, default=256)
+a = ap.parse_args()
+S, n = a.symbols, a.hours
+m = (n - 1) * 60 + 1
+r = np.random.default_rng(0)
+xk = np.tile(np.arange(n, dtype=np.float64) * 60.0, S)
+yk = r.uniform(0.2, 1.0, (3, S * n)); yk[:, r.random(S * n) < 0.05] = np.nan
+koff = (np.arange(S + 1) * n).astype(np.int64); qoff = (np.arange(S + 1) * m).astype(np.int64)
+d = lambda v: torch.from_numpy(v).cuda()
+xk_d, yk_d, koff_d, qoff_d = d(xk), d(yk), d(koff), d(qoff)
+valid = d((r.random((9, S * n)) > 0.02).astype(np.uint8)); pos = d((xk).astype(np.int64))
+def dev_step():
+    engine.interp1d_batch(xk_d, yk_d, koff_d, qoff_d, S * m, a.method)
+    engine.ffill_index_batch(pos, koff_d, valid, qoff_d, S * m)
+for _ in range(3): dev_step()
+torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): dev_step()
+e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 10
+bytes_ = S * (8 * n * 4 + 9 * n + 8 * n) + S * m * (3 * 8 + 9 * 4)       # knots + masks in, 3 f64 + 9 int32 index columns out
+res = {"workload": f"{S} symbols x {n} hourly rows -> {m} minute rows, 3 channels + 9 ffill index columns", "method": a.method,
+       "device": {"ms": ms, "symbols_per_s": S / ms * 1e3, "rows_per_s": S * m / ms * 1e3, "GBps": bytes_ / ms / 1e6, "frac_of_8TBps": bytes_ / ms / 1e6 / 8000}}
+frames = [synthetic_symbol(f"s{i}", n, seed=i) for i in range(a.e2e)]
+iv = IVInterpolator(a.method)
+iv.interpolate_batch(frames[:8])
+t0 = time.perf_counter(); out = iv.interpolate_batch(frames); dt = time.perf_counter() - t0
+res["end_to_end_batch"] = {"symbols": a.e2e, "symbols_per_s": a.e2e / dt, "rows_per_s": sum(len(o) for o in out) / dt}
+t0 = time.perf_counter(); [iv.interpolate_symbol(f) for f in frames[:32]]; dt1 = time.perf_counter() - t0
+res["end_to_end_single"] = {"symbols_per_s": 32 / dt1}
+import ref_symbol
+t0 = time.perf_counter(); k = 0
+while time.perf_counter() - t0 < 5: ref_symbol.interpolate_symbol(frames[k % len(frames)], a.method, 10); k += 1
+res["cpu_reference_shaped"] = {"symbols_per_s": k / (time.perf_counter() - t0), "cores": 1, "kind": "port (oracle/ref_symbol.py, pandas bookkeeping + NumPy oracle)"}
+print(json.dumps(res))
