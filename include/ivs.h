@@ -112,6 +112,27 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
                           const double* Tq, int64_t tq_stride, int32_t mT,
                           double* out, int32_t* status, int32_t method, int32_t flags, void* stream);
 
+/*
+ * Black-Scholes Greeks epilogue (reference src/interpolation/greeks.py:12-43, BlackScholesGreeks.calculate_greeks):
+ * elementwise over n options.  is_put [n] (1 = put) or NULL -> every option uses default_is_put.
+ * theta is per day (/365), vega and rho per 1 % (/100), put rho without sign flip -- all as the reference.
+ */
+int ivs_bs_greeks_f64(const double* S, const double* K, const double* T, const double* r, const double* sigma,
+                      const uint8_t* is_put, int32_t default_is_put, int64_t n, double* delta, double* gamma,
+                      double* theta, double* vega, double* rho, void* stream);
+
+/*
+ * N-minute candle aggregation (reference src/candle_reconstruction/core.py:68-88) for S symbols (CSR series_off [S+1],
+ * rows sorted by timestamp within a symbol).  For every input row i: if it is the first row of its
+ * floor(ts / freq_ns) bucket, out_*[i] holds the bucket's candle (open = first non-NaN, high = max, low = min,
+ * close = last non-NaN, volume = Kahan sum in row order, like pandas) and out_count[i] its row count; otherwise
+ * out_count[i] = 0.  The caller keeps the rows with out_count >= N (incomplete groups are dropped, core.py:86-88).
+ */
+int ivs_candle_aggregate_f64(const int64_t* ts_ns, const double* open, const double* high, const double* low,
+                             const double* close, const double* volume, const int64_t* series_off, int64_t n_series,
+                             int64_t n_rows, int64_t freq_ns, int64_t* out_ts, double* out_open, double* out_high,
+                             double* out_low, double* out_close, double* out_volume, int32_t* out_count, void* stream);
+
 /* name of the kernel the last ivs_surface_batch_f64 call on this thread dispatched to (host string) */
 const char* ivs_last_kernel(void);
 

@@ -7,6 +7,8 @@
 #include <cstring>
 
 #include "../../include/ivs.h"
+#include "ivs_candles.hpp"
+#include "ivs_greeks.hpp"
 #include "ivs_interp1d.hpp"
 #include "ivs_surface_dense.hpp"
 #include "ivs_surface_generic.hpp"
@@ -130,6 +132,40 @@ int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const 
     hipLaunchKernelGGL(ivs::ffill_index_kernel, dim3((unsigned)((total_queries + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p);
     return check_launch("ffill_index_kernel");
+}
+
+int ivs_candle_aggregate_f64(const int64_t* ts_ns, const double* open, const double* high, const double* low,
+                             const double* close, const double* volume, const int64_t* series_off, int64_t n_series,
+                             int64_t n_rows, int64_t freq_ns, int64_t* out_ts, double* out_open, double* out_high,
+                             double* out_low, double* out_close, double* out_volume, int32_t* out_count, void* stream) {
+    g_err[0] = 0;
+    if (n_rows < 0 || n_series < 0 || freq_ns <= 0) return fail(IVS_EINVAL, "ivs_candle_aggregate_f64: bad size / frequency");
+    if (n_rows == 0 || n_series == 0) return IVS_OK;
+    if (!ts_ns || !open || !high || !low || !close || !volume || !series_off || !out_ts || !out_open || !out_high ||
+        !out_low || !out_close || !out_volume || !out_count)
+        return fail(IVS_EINVAL, "ivs_candle_aggregate_f64: null pointer");
+    if ((n_rows + 255) / 256 > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_candle_aggregate_f64: too many rows");
+    ivs::CandleParams p{ts_ns, open, high, low, close, volume, series_off, n_series, n_rows, freq_ns,
+                        out_ts, out_open, out_high, out_low, out_close, out_volume, out_count};
+    hipLaunchKernelGGL(ivs::candle_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    return check_launch("candle_kernel");
+}
+
+int ivs_bs_greeks_f64(const double* S, const double* K, const double* T, const double* r, const double* sigma,
+                      const uint8_t* is_put, int32_t default_is_put, int64_t n, double* delta, double* gamma,
+                      double* theta, double* vega, double* rho, void* stream) {
+    g_err[0] = 0;
+    if (n < 0) return fail(IVS_EINVAL, "ivs_bs_greeks_f64: negative size");
+    if (n == 0) return IVS_OK;
+    if (!S || !K || !T || !r || !sigma || !delta || !gamma || !theta || !vega || !rho)
+        return fail(IVS_EINVAL, "ivs_bs_greeks_f64: null pointer");
+    ivs::GreeksParams p{S, K, T, r, sigma, is_put, default_is_put, n, delta, gamma, theta, vega, rho};
+    int64_t blocks = (n + 255) / 256;
+    int64_t cap = (int64_t)num_cu() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ivs::greeks_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return check_launch("greeks_kernel");
 }
 
 int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_stride, int32_t nK,

@@ -117,3 +117,39 @@ def ffill_index_batch(src_pos, src_off, valid, q_off, total_q: int, stream=None)
                                    S, total_q, _ptr(idx), total_q, _stream(torch, stream))
     _lib.check(rc, "ivs_ffill_index_batch")
     return idx
+
+
+def bs_greeks(S, K, T, r, sigma, is_put=None, default_is_put: bool = False, stream=None):
+    """Black-Scholes Greeks on the device.  All inputs CUDA float64 tensors of one shape (is_put: uint8 or None).
+    Returns dict(delta, gamma, theta, vega, rho) of tensors with that shape."""
+    torch = require_device()
+    lib = _lib.load()
+    ins = [_f64(torch, t, n) for t, n in zip((S, K, T, r, sigma), ("S", "K", "T", "r", "sigma"))]
+    n = ins[0].numel()
+    if any(t.numel() != n for t in ins):
+        raise ValueError("all inputs must have the same number of elements")
+    if is_put is not None:
+        is_put = is_put.to(torch.uint8).contiguous()
+    outs = [torch.empty_like(ins[0]) for _ in range(5)]
+    rc = lib.ivs_bs_greeks_f64(*[_ptr(t) for t in ins], _ptr(is_put), int(bool(default_is_put)), n,
+                               *[_ptr(t) for t in outs], _stream(torch, stream))
+    _lib.check(rc, "ivs_bs_greeks_f64")
+    return dict(zip(("delta", "gamma", "theta", "vega", "rho"), outs))
+
+
+def candle_aggregate(ts_ns, o, h, l, c, v, series_off, freq_minutes: int, stream=None):
+    """Sparse N-minute aggregation on the device (see ivs_candle_aggregate_f64).  ts_ns int64, OHLCV float64, series_off
+    int64 [S+1]; all CUDA tensors.  Returns (out_ts, open, high, low, close, volume, count) of length n."""
+    torch = require_device()
+    lib = _lib.load()
+    n = ts_ns.numel()
+    S = series_off.numel() - 1
+    cols = [_f64(torch, t, nm) for t, nm in zip((o, h, l, c, v), "ohlcv")]
+    out_ts = torch.empty(n, dtype=torch.int64, device=ts_ns.device)
+    outs = [torch.empty(n, dtype=torch.float64, device=ts_ns.device) for _ in range(5)]
+    cnt = torch.empty(n, dtype=torch.int32, device=ts_ns.device)
+    rc = lib.ivs_candle_aggregate_f64(_ptr(ts_ns.contiguous()), *[_ptr(t) for t in cols], _ptr(series_off), S, n,
+                                      int(freq_minutes) * 60_000_000_000, _ptr(out_ts), *[_ptr(t) for t in outs], _ptr(cnt),
+                                      _stream(torch, stream))
+    _lib.check(rc, "ivs_candle_aggregate_f64")
+    return (out_ts, *outs, cnt)
