@@ -11,6 +11,7 @@
 #include "ivs_greeks.hpp"
 #include "ivs_interp1d.hpp"
 #include "ivs_surface_dense.hpp"
+#include "ivs_surface_dense_var.hpp"
 #include "ivs_surface_generic.hpp"
 
 namespace {
@@ -205,6 +206,14 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
             return check_launch(name);
         }
         if (rc < 0) return fail(IVS_ELAUNCH, "ivs_surface_batch_f64: dense dispatch failed");
+        if (!g_stamp_buf) {
+            rc = ivs::launch_surface_dense_var(p, num_cu(), st, &name);
+            if (rc == 1) {
+                g_last_kernel = name;
+                return check_launch(name);
+            }
+            if (rc < 0) return fail(IVS_ELAUNCH, "ivs_surface_batch_f64: dense-var dispatch failed");
+        }
     }
 
     if (!ivs::launch_surface_generic<false>(p, num_cu(), st))

@@ -298,6 +298,161 @@ struct TqTables {
     __device__ __forceinline__ int n_iv(int j) const { return (int)(((j < 8 ? iv_lo : iv_hi) >> (8 * (j & 7))) & 0xffull); }
 };
 
+// T-phase: maturity-direction factor tables (LDS, TT) + per-query-row weights (registers, lane = tq; also W in LDS
+// when WLDS) + row counts per class.  Needs mT <= 64.  All 64 lanes must call it; ends with a barrier.
+template <int METHOD, bool WLDS>
+__device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tqb, int mT, int lane, double* Tsh,
+                                              double* TT, double* W, TqTables& tt) {
+    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool w_lds = WLDS;
+    if (lane < DT) Tsh[lane] = Tb[lane];
+    __syncthreads();
+    if (CUB) {
+        double al, cp, pp, qq, rdx;
+        factor_tables<DT>(Tsh, lane, al, cp, pp, qq, rdx);
+        if (lane < DT) { TT[lane * 4 + 0] = pp; TT[lane * 4 + 1] = qq; TT[lane * 4 + 2] = al; TT[lane * 4 + 3] = cp; }
+    }
+    const int tq = lane;
+    const bool act = tq < mT;
+    const double x = act ? Tqb[tq] : __builtin_inf();
+    int j = -1;                                           // largest j with Tsh[j] <= x, or -1
+    if (Tsh[0] <= x) {
+        j = 0;
+#pragma unroll
+        for (int st = 8; st >= 1; st >>= 1) if (Tsh[j + st] <= x) j += st;
+    }
+    int code;
+    const double tl = Tsh[DT - 1];
+    if (j < 0) code = TQ_LEFT;
+    else if (j >= DT - 1) {
+        if (METHOD == IVS_LINEAR) code = TQ_HOLD;
+        else if (METHOD == IVS_SLINEAR) code = (x == tl) ? TQ_HOLD : TQ_NAN;
+        else if (METHOD == IVS_CUBIC) code = (x == tl) ? DT - 2 : TQ_NAN;
+        else code = DT - 2;
+    } else code = j;
+    const int jj = code >= 0 && code <= DT - 2 ? code : 0;
+    const double x0 = Tsh[jj], x1 = Tsh[jj + 1];
+    if (CUB) {
+        const double h = x1 - x0, u = x - x0, t = u / h, omt = 1.0 - t;
+        tt.w0 = (1.0 + 2.0 * t) * omt * omt;              // h00
+        tt.w1 = t * t * (3.0 - 2.0 * t);                  // h01
+        tt.w2 = u * omt * omt;                            // h * h10
+        tt.w3 = u * t * (t - 1.0);                        // h * h11
+    } else {
+        tt.w0 = x; tt.w1 = x0; tt.w2 = x1; tt.w3 = refined_rcp(x1 - x0);
+    }
+    if (w_lds && act) {
+        *reinterpret_cast<double2*>(W + tq * 4) = double2{tt.w0, tt.w1};
+        *reinterpret_cast<double2*>(W + tq * 4 + 2) = double2{tt.w2, tt.w3};
+    }
+    tt.n_left = __popcll(__ballot(act && code == TQ_LEFT));
+    tt.n_hold = __popcll(__ballot(act && code == TQ_HOLD));
+    tt.n_nan = __popcll(__ballot(act && code == TQ_NAN));
+    tt.iv_lo = 0; tt.iv_hi = 0;
+#pragma unroll
+    for (int jv = 0; jv < DT - 1; ++jv) {
+        const unsigned long long n = (unsigned long long)__popcll(__ballot(act && code == jv));
+        if (jv < 8) tt.iv_lo |= n << (8 * jv); else tt.iv_hi |= n << (8 * (jv - 8));
+    }
+    // the row loops below walk the classes in order: needs ascending, NaN-free Tq
+    const double xprev = dpp_f64<DPP_WAVE_SHR1>(-__builtin_inf(), x);
+    tt.unsorted = __ballot(act && ((x < xprev) || !(x == x))) != 0ull;
+    __syncthreads();
+}
+
+// Maturity direction for one block of 64 output strikes (q-lane): z[t] = strike-pass value of row t at the lane's
+// strike.  Solves the lane's 16-knot system in registers (cubic) and walks the output rows class by class
+// (left-NaN rows, rows per maturity interval, hold rows, right-NaN rows), storing 512-B rows through a
+// wave-uniform base pointer.
+template <int METHOD, bool WLDS, class StampFn>
+__device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const TqTables& tt, const double* TT,
+                                                    const double* W, double* outb, int q0, int lane, bool act, int mT,
+                                                    int mK, StampFn&& stamp) {
+    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool w_lds = WLDS;
+    const double nanv = __builtin_nan("");
+    // ---- maturity direction (q-lane, registers).  Row pointers are wave-uniform (scalar base),
+    // the lane contributes only its 32-bit column offset.
+    int tq = 0;
+    auto put = [&](int row, double v) {
+        double* rp = outb + (int64_t)row * mK + q0;           // uniform
+        if (act) rp[lane] = v;
+    };
+    for (int c = 0; c < tt.n_left; ++c, ++tq) put(tq, nanv);
+    // weights of row tq: LDS broadcast (prefetched one row ahead) when mT <= 16, else readlane
+    const double2* W2 = reinterpret_cast<const double2*>(W);
+    double2 wa_n = double2{0.0, 0.0}, wb_n = double2{0.0, 0.0};
+    if (w_lds) { const int t0 = tq < mT ? tq : 0; wa_n = W2[2 * t0]; wb_n = W2[2 * t0 + 1]; }
+    auto weights = [&](int row, double& a0, double& a1, double& a2, double& a3) {
+        if (w_lds) {
+            a0 = wa_n.x; a1 = wa_n.y; a2 = wb_n.x; a3 = wb_n.y;
+            const int nx = row + 1 < mT ? row + 1 : row;      // prefetch the next row's weights
+            wa_n = W2[2 * nx]; wb_n = W2[2 * nx + 1];
+        } else {
+            a0 = readlane_f64(tt.w0, row); a1 = readlane_f64(tt.w1, row);
+            a2 = readlane_f64(tt.w2, row); a3 = readlane_f64(tt.w3, row);
+        }
+    };
+    if (CUB) {
+        double s[DT];
+        double prev = 0.0;
+        {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
+            constexpr int LA = 4;
+            double2 tpq[4], tac[4];
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                tpq[i] = *reinterpret_cast<const double2*>(TT + i * 4);
+                tac[i] = *reinterpret_cast<const double2*>(TT + i * 4 + 2);
+            }
+            double cpv[DT];                                // CP_i, kept for the backward sweep
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const double2 pq = tpq[i & 3], ac = tac[i & 3];
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + LA < DT) {
+                    tpq[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4);
+                    tac[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4 + 2);
+                }
+                // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
+                const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
+                s[i] = prev;
+                cpv[i] = ac.y;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = DT - 2; i >= 0; --i) s[i] = s[i] - cpv[i] * s[i + 1];
+        }
+        stamp(4);
+#pragma unroll
+        for (int jv = 0; jv < DT - 1; ++jv) {
+            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+                double a0, a1, a2, a3;
+                weights(tq, a0, a1, a2, a3);
+                put(tq, a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int jv = 0; jv < DT - 1; ++jv) {
+            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+                double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
+                weights(tq, xt, t0, t1, rdt);
+                const double dt = t1 - t0;
+                bool slow = !div_safe(dt);
+                double r = lerp_fast(xt, t0, z[jv], z[jv + 1], dt, rdt, slow);
+                if (__builtin_expect(__ballot(slow) != 0ull, 0)) {
+                    if (slow) r = lerp_np(xt, t0, z[jv], t1, z[jv + 1]);
+                }
+                put(tq, r);
+            }
+        }
+    }
+    for (int c = 0; c < tt.n_hold; ++c, ++tq) put(tq, z[DT - 1]);
+    for (int c = 0; c < tt.n_nan; ++c, ++tq) put(tq, nanv);
+}
+
 template <int METHOD, bool TSHARED, bool WLDS, bool STAMP = false>
 __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, unsigned long long* dbg = nullptr) {
     constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
@@ -323,68 +478,12 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
     double* TT = RDX + 64;             // [16][4] = {PP, QQ, AL, CP} of the maturity system
     double* W = TT + 64;               // [16][4] query-row weights (only when mT <= 16)
     double* Tsh = TSHARED ? Y : S;     // T-phase scratch: the plane that is free at the time it runs
-    constexpr bool w_lds = WLDS;       // host guarantees mT <= D_WLDS_MAX_MT when set
 
     constexpr bool t_shared = TSHARED;   // T and Tq shared by the whole batch: T-phase hoisted out of the loop
     const double nanv = __builtin_nan("");
 
-    // ---- T-phase: maturity-direction tables (LDS) + per-query-row weights (registers, lane = tq)
     TqTables tt;
-    auto t_phase = [&](const double* Tb, const double* Tqb) {
-        if (lane < DT) Tsh[lane] = Tb[lane];
-        __syncthreads();
-        if (CUB) {
-            double al, cp, pp, qq, rdx;
-            factor_tables<DT>(Tsh, lane, al, cp, pp, qq, rdx);
-            if (lane < DT) { TT[lane * 4 + 0] = pp; TT[lane * 4 + 1] = qq; TT[lane * 4 + 2] = al; TT[lane * 4 + 3] = cp; }
-        }
-        const int tq = lane;
-        const bool act = tq < mT;
-        const double x = act ? Tqb[tq] : __builtin_inf();
-        int j = -1;                                           // largest j with Tsh[j] <= x, or -1
-        if (Tsh[0] <= x) {
-            j = 0;
-#pragma unroll
-            for (int st = 8; st >= 1; st >>= 1) if (Tsh[j + st] <= x) j += st;
-        }
-        int code;
-        const double tl = Tsh[DT - 1];
-        if (j < 0) code = TQ_LEFT;
-        else if (j >= DT - 1) {
-            if (METHOD == IVS_LINEAR) code = TQ_HOLD;
-            else if (METHOD == IVS_SLINEAR) code = (x == tl) ? TQ_HOLD : TQ_NAN;
-            else if (METHOD == IVS_CUBIC) code = (x == tl) ? DT - 2 : TQ_NAN;
-            else code = DT - 2;
-        } else code = j;
-        const int jj = code >= 0 && code <= DT - 2 ? code : 0;
-        const double x0 = Tsh[jj], x1 = Tsh[jj + 1];
-        if (CUB) {
-            const double h = x1 - x0, u = x - x0, t = u / h, omt = 1.0 - t;
-            tt.w0 = (1.0 + 2.0 * t) * omt * omt;              // h00
-            tt.w1 = t * t * (3.0 - 2.0 * t);                  // h01
-            tt.w2 = u * omt * omt;                            // h * h10
-            tt.w3 = u * t * (t - 1.0);                        // h * h11
-        } else {
-            tt.w0 = x; tt.w1 = x0; tt.w2 = x1; tt.w3 = refined_rcp(x1 - x0);
-        }
-        if (w_lds && act) {
-            *reinterpret_cast<double2*>(W + tq * 4) = double2{tt.w0, tt.w1};
-            *reinterpret_cast<double2*>(W + tq * 4 + 2) = double2{tt.w2, tt.w3};
-        }
-        tt.n_left = __popcll(__ballot(act && code == TQ_LEFT));
-        tt.n_hold = __popcll(__ballot(act && code == TQ_HOLD));
-        tt.n_nan = __popcll(__ballot(act && code == TQ_NAN));
-        tt.iv_lo = 0; tt.iv_hi = 0;
-#pragma unroll
-        for (int jv = 0; jv < DT - 1; ++jv) {
-            const unsigned long long n = (unsigned long long)__popcll(__ballot(act && code == jv));
-            if (jv < 8) tt.iv_lo |= n << (8 * jv); else tt.iv_hi |= n << (8 * (jv - 8));
-        }
-        // the row loops below walk the classes in order: needs ascending, NaN-free Tq
-        const double xprev = dpp_f64<DPP_WAVE_SHR1>(-__builtin_inf(), x);
-        tt.unsorted = __ballot(act && ((x < xprev) || !(x == x))) != 0ull;
-        __syncthreads();
-    };
+    auto t_phase = [&](const double* Tb, const double* Tqb) { dense_t_phase<METHOD, WLDS>(Tb, Tqb, mT, lane, Tsh, TT, W, tt); };
 
     if (t_shared) t_phase(p.T, p.Tq);
 
@@ -518,86 +617,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
                 }
             }
             stamp(3);
-            // ---- maturity direction (q-lane, registers).  Row pointers are wave-uniform (scalar base),
-            // the lane contributes only its 32-bit column offset.
-            int tq = 0;
-            auto put = [&](int row, double v) {
-                double* rp = outb + (int64_t)row * mK + q0;           // uniform
-                if (act) rp[lane] = v;
-            };
-            for (int c = 0; c < tt.n_left; ++c, ++tq) put(tq, nanv);
-            // weights of row tq: LDS broadcast (prefetched one row ahead) when mT <= 16, else readlane
-            const double2* W2 = reinterpret_cast<const double2*>(W);
-            double2 wa_n = double2{0.0, 0.0}, wb_n = double2{0.0, 0.0};
-            if (w_lds) { const int t0 = tq < mT ? tq : 0; wa_n = W2[2 * t0]; wb_n = W2[2 * t0 + 1]; }
-            auto weights = [&](int row, double& a0, double& a1, double& a2, double& a3) {
-                if (w_lds) {
-                    a0 = wa_n.x; a1 = wa_n.y; a2 = wb_n.x; a3 = wb_n.y;
-                    const int nx = row + 1 < mT ? row + 1 : row;      // prefetch the next row's weights
-                    wa_n = W2[2 * nx]; wb_n = W2[2 * nx + 1];
-                } else {
-                    a0 = readlane_f64(tt.w0, row); a1 = readlane_f64(tt.w1, row);
-                    a2 = readlane_f64(tt.w2, row); a3 = readlane_f64(tt.w3, row);
-                }
-            };
-            if (CUB) {
-                double s[DT];
-                double prev = 0.0;
-                {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
-                    constexpr int LA = 4;
-                    double2 tpq[4], tac[4];
-#pragma unroll
-                    for (int i = 0; i < LA; ++i) {
-                        tpq[i] = *reinterpret_cast<const double2*>(TT + i * 4);
-                        tac[i] = *reinterpret_cast<const double2*>(TT + i * 4 + 2);
-                    }
-                    double cpv[DT];                                // CP_i, kept for the backward sweep
-#pragma unroll
-                    for (int i = 0; i < DT; ++i) {
-                        const double2 pq = tpq[i & 3], ac = tac[i & 3];
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (i + LA < DT) {
-                            tpq[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4);
-                            tac[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4 + 2);
-                        }
-                        // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
-                        const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
-                        const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
-                        prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
-                        s[i] = prev;
-                        cpv[i] = ac.y;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int i = DT - 2; i >= 0; --i) s[i] = s[i] - cpv[i] * s[i + 1];
-                }
-                stamp(4);
-#pragma unroll
-                for (int jv = 0; jv < DT - 1; ++jv) {
-                    for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
-                        double a0, a1, a2, a3;
-                        weights(tq, a0, a1, a2, a3);
-                        put(tq, a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int jv = 0; jv < DT - 1; ++jv) {
-                    for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
-                        double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
-                        weights(tq, xt, t0, t1, rdt);
-                        const double dt = t1 - t0;
-                        bool slow = !div_safe(dt);
-                        double r = lerp_fast(xt, t0, z[jv], z[jv + 1], dt, rdt, slow);
-                        if (__builtin_expect(__ballot(slow) != 0ull, 0)) {
-                            if (slow) r = lerp_np(xt, t0, z[jv], t1, z[jv + 1]);
-                        }
-                        put(tq, r);
-                    }
-                }
-            }
-            for (int c = 0; c < tt.n_hold; ++c, ++tq) put(tq, z[DT - 1]);
-            for (int c = 0; c < tt.n_nan; ++c, ++tq) put(tq, nanv);
+            dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, act, mT, mK, stamp);
             stamp(5);
         }
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;

@@ -1,0 +1,441 @@
+// Dense fast path for VARIABLE strike counts: 4 <= nK <= 128 per surface (uniform batches with nK != 64 and
+// ragged CSR batches, BASELINE config 5), 16 maturities, shared T/Tq, no missing quotes.
+//
+// Same three-layout scheme as ivs_surface_dense.hpp, with the strike count n a run-time value:
+//   * NKB = 1 handles surfaces with n <= 64, NKB = 2 those with 65..128 (two 64-strike blocks per k-lane, two
+//     16-strike segments per rs-lane); a ragged batch is served by one launch per class, each launch skipping the
+//     surfaces of the other class (wave-uniform test on k_off);
+//   * knots beyond n are neutral elements: +inf in the strike array (searches stop), identity matrices in the
+//     pivot scan, 1.0 in the segment products, masked steps in the sweeps;
+//   * the last row of the not-a-knot system sits at a run-time position, so the sweeps use a three-tap right-hand
+//     side  r_i = PM_i*dy_{i-2} + PP_i*dy_{i-1} + QQ_i*dy_i  (PM is zero except on the last row).
+// Surfaces outside [4,128], with a NaN quote, or batches with unsorted Tq are tagged for the generic redo pass.
+#pragma once
+#include "ivs_surface_dense.hpp"
+
+namespace ivs {
+
+constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST3 = 0xFF;   // quad_perm:[0,0,0,0] / [3,3,3,3]
+
+template <int NKB>
+__host__ __device__ inline size_t dense_var_lds_bytes(int mT) {
+    // Y, S planes [16][NKB*72]; Ksh [NKB*64 + 8]; RDX [NKB*64]; TT [16][4]; W [16][4] when mT <= 16
+    return (size_t)(2 * DT * NKB * 72 + NKB * 64 + 8 + NKB * 64 + 64 + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
+}
+
+// Factor tables for n knots (run time) spread over NKB blocks of 64 lanes.  Tables are written at d_sl(i), i < n.
+template <int NKB>
+__device__ __forceinline__ void factor_tables_var(const double* X, int n, int lane, double* AL, double* CP, double* PP,
+                                                  double* QQ, double* PM, double* PI, double* PSI, double* RDX) {
+    double c00 = 1.0, c01 = 0.0, c10 = 0.0, c11 = 1.0;          // product of all matrices of the previous blocks
+    double carry_crb = 0.0, carry_rdx = 0.0, carry_rdx_prev = 0.0;
+#pragma unroll
+    for (int blk = 0; blk < NKB; ++blk) {
+        const int ir = blk * 64 + lane;
+        const bool in = ir < n;
+        const int i = in ? ir : n - 1;
+        const double x0 = X[i];
+        const double xp = X[i + 1 < n ? i + 1 : n - 1];
+        const double xpp = X[i + 2 < n ? i + 2 : n - 1];
+        const double xm = X[i > 0 ? i - 1 : 0];
+        const double xmm = X[i > 1 ? i - 2 : 0];
+        const double dxc = xp - x0, dxm = x0 - xm, dxp = xpp - xp, dxmm = xm - xmm;
+        const double rdxc = refined_rcp(dxc);
+        const bool first = ir == 0, last = ir == n - 1;
+        double a, b, c;
+        if (first) { a = 0.0; b = dxp; c = dxc + dxp; }
+        else if (last) { a = dxmm + dxm; b = dxmm; c = 0.0; }
+        else { a = dxc; b = 2.0 * (dxm + dxc); c = dxm; }
+        if (!in) { a = 0.0; b = 1.0; c = 0.0; }
+        const double rb = refined_rcp(b);
+        const double crb = c * rb;
+        double crb_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, crb);
+        if (blk > 0 && lane == 0) crb_prev = carry_crb;
+        const bool ident = first || !in;
+        const double g = ident ? 0.0 : a * rb * crb_prev;
+        double p00 = 1.0, p01 = ident ? 0.0 : -g, p10 = ident ? 0.0 : 1.0, p11 = ident ? 1.0 : 0.0;
+        scan_mat2<64>(p00, p01, p10, p11, lane);
+        if (blk > 0) {                                           // append the previous blocks' product on the right
+            const double n00 = p00 * c00 + p01 * c10, n01 = p00 * c01 + p01 * c11;
+            const double n10 = p10 * c00 + p11 * c10, n11 = p10 * c01 + p11 * c11;
+            p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+        }
+        const double num = p00 + p01, den = p10 + p11;
+        const double rw = first ? rb : den * rb * refined_rcp(num);
+        const double al = a * rw, cp = c * rw;
+        double rdx_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, rdxc);
+        if (blk > 0 && lane == 0) rdx_prev = carry_rdx;
+        const double rdx_next = dpp_f64<DPP_WAVE_SHL1>(0.0, rdxc);          // only row 0 uses it (never crosses a block)
+        double rdxmm = dpp_f64<DPP_WAVE_SHR1>(0.0, rdx_prev);
+        if (blk > 0 && lane == 0) rdxmm = carry_rdx_prev;
+        const double d = first ? dxc + dxp : dxmm + dxm;
+        const double rd = refined_rcp(d);
+        double pm = 0.0, pp, qq;
+        if (first) {
+            pp = (dxc + 2.0 * d) * dxp * rdxc * rd * rw;         // * dy_0
+            qq = dxc * dxc * rdx_next * rd * rw;                 // * dy_1
+        } else if (last) {
+            pm = dxm * dxm * rdxmm * rd * rw;                    // * dy_{n-3}
+            pp = (2.0 * d + dxm) * dxmm * rdx_prev * rd * rw;    // * dy_{n-2}
+            qq = 0.0;
+        } else {
+            pp = 3.0 * dxc * rdx_prev * rw;                      // * dy_{i-1}
+            qq = 3.0 * dxm * rdxc * rw;                          // * dy_i
+        }
+        const double pi = seg16_prefix_prod(in ? -al : 1.0, lane);
+        const double psi = seg16_suffix_prod(in ? -cp : 1.0, lane);
+        if (in) {
+            const int kl = d_sl(ir);
+            AL[kl] = al; CP[kl] = cp; PP[kl] = pp; QQ[kl] = qq; PM[kl] = pm; PI[kl] = pi; PSI[kl] = psi;
+            RDX[ir] = rdxc;
+        }
+        if (blk + 1 < NKB) {
+            c00 = readlane_f64(p00, 63); c01 = readlane_f64(p01, 63); c10 = readlane_f64(p10, 63); c11 = readlane_f64(p11, 63);
+            carry_crb = readlane_f64(crb, 63); carry_rdx = readlane_f64(rdxc, 63); carry_rdx_prev = readlane_f64(rdx_prev, 63);
+        }
+    }
+}
+
+// Slopes of all 16 rows for run-time n.  Y/S planes have row stride RS = NKB*72; tables alias the S plane.
+template <int NKB>
+__device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double* S, const double* Ksh, double* RDX, int n,
+                                                        int lane) {
+    constexpr int RS = NKB * 72;
+    double* AL = S;
+    double* CP = S + RS;
+    double* PP = S + 2 * RS;
+    double* QQ = S + 3 * RS;
+    double* PM = S + 4 * RS;
+    double* PI = S + 5 * RS;
+    double* PSI = S + 6 * RS;
+    factor_tables_var<NKB>(Ksh, n, lane, AL, CP, PP, QQ, PM, PI, PSI, RDX);
+    __syncthreads();
+    const int rs_t = lane >> 2, rs_seg = lane & 3;
+    double d[NKB][16];
+    int len[NKB];
+    double endv[NKB], pie[NKB], din[NKB];
+    // ---- local forward sweeps
+#pragma unroll
+    for (int u = 0; u < NKB; ++u) {
+        const int sg = rs_seg + 4 * u, kb = 16 * sg, kp = 18 * sg;
+        int ln = n - kb; ln = ln < 0 ? 0 : (ln > 16 ? 16 : ln);
+        len[u] = ln;
+        const double* yrow = Y + rs_t * RS;
+        double y[19];                                          // y[j] = y_{kb + j - 2}
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double2 v = *reinterpret_cast<const double2*>(yrow + kp + 2 * c);
+            y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
+        }
+        y[0] = kb >= 2 ? yrow[d_sl(kb - 2)] : 0.0;
+        y[1] = kb >= 1 ? yrow[d_sl(kb - 1)] : 0.0;
+        y[18] = kb + 16 < n ? yrow[d_sl(kb + 16)] : 0.0;
+        double prev = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            double dM = y[m + 1] - y[m], dA = y[m + 2] - y[m + 1], dB = y[m + 3] - y[m + 2];   // dy_{i-2}, dy_{i-1}, dy_i
+            if (u == 0 && m == 0) {                            // row 0 of the system uses (dy_0, dy_1)
+                const double e = y[4] - y[3];
+                if (rs_seg == 0) { dA = dB; dB = e; }
+            }
+            if (m < ln) {
+                const double r = PM[kp + m] * dM + PP[kp + m] * dA + QQ[kp + m] * dB;
+                prev = r - AL[kp + m] * prev;
+            }
+            d[u][m] = prev;
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        endv[u] = prev;
+        pie[u] = ln > 0 ? PI[kp + ln - 1] : 1.0;
+    }
+    // ---- forward carries across the 4*NKB logical segments (0,1,2,3 of u = 0, then of u = 1, ...)
+    double carry = 0.0;
+#pragma unroll
+    for (int u = 0; u < NKB; ++u) {
+        double di = rs_seg == 0 ? carry : 0.0;
+        double tot = endv[u] + pie[u] * di;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const double v = dpp_f64<DPP_ROW_SHR(1)>(0.0, tot);
+            if (rs_seg == j) { di = v; tot = endv[u] + pie[u] * di; }
+        }
+        din[u] = di;
+        carry = dpp_f64<DPP_QUAD_BCAST3>(0.0, tot);            // value at the end of logical segment 3 + 4u
+    }
+    // ---- local backward sweeps (with the forward fix-up folded in)
+    double firstv[NKB], psb[NKB], sin_[NKB];
+#pragma unroll
+    for (int u = NKB - 1; u >= 0; --u) {
+        const int kp = 18 * (rs_seg + 4 * u);
+        const int ln = len[u];
+        double nxt = 0.0;
+#pragma unroll
+        for (int m = 15; m >= 0; --m) {
+            if (m < ln) {
+                const double dp = d[u][m] + PI[kp + m] * din[u];
+                nxt = dp - CP[kp + m] * nxt;
+                d[u][m] = nxt;
+            }
+            if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        firstv[u] = ln > 0 ? d[u][0] : 0.0;
+        psb[u] = ln > 0 ? PSI[kp] : 1.0;
+    }
+    carry = 0.0;
+#pragma unroll
+    for (int u = NKB - 1; u >= 0; --u) {
+        double si = rs_seg == 3 ? carry : 0.0;
+        double tot = firstv[u] + psb[u] * si;
+#pragma unroll
+        for (int j = 2; j >= 0; --j) {
+            const double v = dpp_f64<DPP_ROW_SHL(1)>(0.0, tot);
+            if (rs_seg == j) { si = v; tot = firstv[u] + psb[u] * si; }
+        }
+        sin_[u] = si;
+        carry = dpp_f64<DPP_QUAD_BCAST0>(0.0, tot);            // slope at the first knot of logical segment 4u
+    }
+#pragma unroll
+    for (int u = 0; u < NKB; ++u) {
+        const int kp = 18 * (rs_seg + 4 * u);
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < len[u]) d[u][m] = d[u][m] + PSI[kp + m] * sin_[u];
+    }
+    __syncthreads();                                           // table reads done: the S plane may be overwritten
+#pragma unroll
+    for (int u = 0; u < NKB; ++u) {
+        double* srow = S + rs_t * RS + 18 * (rs_seg + 4 * u);
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < len[u]) srow[m] = d[u][m];
+    }
+}
+
+struct VarRange { int lo, hi; };   // strike counts served by a launch
+
+template <int METHOD, int NKB, bool WLDS>
+__global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
+    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr int RS = NKB * 72;
+    constexpr int KCAP = NKB * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int mT = p.mT, mK = p.mK;
+    double* Y = reinterpret_cast<double*>(smem);
+    double* S = Y + DT * RS;
+    double* Ksh = S + DT * RS;             // KCAP + 8 (the tail stays +inf)
+    double* RDX = Ksh + KCAP + 8;
+    double* TT = RDX + KCAP;
+    double* W = TT + 64;
+    const double nanv = __builtin_nan(""), inf = __builtin_inf();
+    auto nostamp = [](int) {};
+
+    TqTables tt;
+    dense_t_phase<METHOD, WLDS>(p.T, p.Tq, mT, lane, Y, TT, W, tt);       // shared T/Tq: once per workgroup
+    if (lane < 8) Ksh[KCAP + lane] = inf;
+
+    constexpr int XQ_REG = 4;
+    double xq_reg[XQ_REG];
+    const bool kq_shared = p.kq_stride == 0;
+    auto load_xq = [&](const double* Kqb) {
+#pragma unroll
+        for (int i = 0; i < XQ_REG; ++i) xq_reg[i] = (i * 64 + lane < mK) ? Kqb[i * 64 + lane] : nanv;
+    };
+    if (kq_shared) load_xq(p.Kq);
+
+    // strike count / offset of surface b; walk to the next surface of this launch's class
+    auto count_of = [&](int64_t b, int64_t& koff) -> int {
+        if (p.k_off) { koff = p.k_off[b]; return (int)(p.k_off[b + 1] - koff); }
+        koff = b * p.k_stride; return p.nK;
+    };
+    auto tag = [&](int64_t b) {
+        if (lane == 0) reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL;
+    };
+    auto seek = [&](int64_t b, int& n, int64_t& koff) -> int64_t {
+        for (; b < p.B; b += gridDim.x) {
+            n = count_of(b, koff);
+            if (n >= range.lo && n <= range.hi) break;
+            if (tag_out_of_range && (n < 4 || n > 128)) tag(b);
+        }
+        return b;
+    };
+
+    double pre[DT * NKB], pre_k[NKB];
+    int n = 0, n_next = 0;
+    int64_t koff = 0, koff_next = 0;
+    auto sigma_of = [&](int64_t b, int64_t ko) -> const double* {
+        return p.k_off ? p.sigma + (int64_t)DT * ko : p.sigma + b * (int64_t)DT * p.nK;
+    };
+    auto issue_loads = [&](int64_t b, int64_t ko, int nn) {
+        const double* sb = sigma_of(b, ko);
+        const double* Kb = p.K + ko;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int blk = 0; blk < NKB; ++blk) {
+                const int k = blk * 64 + lane;
+                pre[t * NKB + blk] = k < nn ? sb[(int64_t)t * nn + k] : 0.0;
+            }
+#pragma unroll
+        for (int blk = 0; blk < NKB; ++blk) { const int k = blk * 64 + lane; pre_k[blk] = k < nn ? Kb[k] : inf; }
+    };
+
+    int64_t b = seek(blockIdx.x, n, koff);
+    if (b < p.B) issue_loads(b, koff, n);
+
+    while (b < p.B) {
+        __syncthreads();
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int blk = 0; blk < NKB; ++blk) {
+                const double v = pre[t * NKB + blk];
+                Y[t * RS + d_sl(blk * 64 + lane)] = v;
+                bad |= !(v == v);
+            }
+#pragma unroll
+        for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
+        double* outb = p.out + b * (int64_t)mT * mK;
+        const double* Kqb = p.Kq + b * p.kq_stride;
+        const int64_t b_next = seek(b + gridDim.x, n_next, koff_next);
+        const bool redo = __ballot(bad) != 0ull || tt.unsorted;
+        if (redo) {
+            tag(b);
+        } else {
+            __syncthreads();
+            if (CUB) {
+                dense_strike_slopes_var<NKB>(Y, S, Ksh, RDX, n, lane);
+                __syncthreads();
+            }
+            if (!kq_shared) load_xq(Kqb);
+        }
+        if (b_next < p.B) issue_loads(b_next, koff_next, n_next);   // next surface flies during evaluation + maturity pass
+        if (!redo) {
+#pragma unroll 1
+            for (int q0 = 0, qb = 0; q0 < mK; q0 += 64, ++qb) {
+                const int q = q0 + lane;
+                const bool act = q < mK;
+                double xq;
+                if (qb < XQ_REG) xq = qb == 0 ? xq_reg[0] : (qb == 1 ? xq_reg[1] : (qb == 2 ? xq_reg[2] : xq_reg[3]));
+                else xq = act ? Kqb[q] : nanv;
+                int j = 0;
+#pragma unroll
+                for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
+#pragma unroll
+                for (int st = 4; st >= 1; st >>= 1) if (Ksh[j + st] <= xq) j += st;
+                const double xl = Ksh[n - 1];
+                const bool left = !(Ksh[0] <= xq);
+                const int jj = j > n - 2 ? n - 2 : j;
+                const double x0 = Ksh[jj], x1 = Ksh[jj + 1];
+                const int o0 = d_sl(jj), o1 = d_sl(jj + 1);
+                double z[DT];
+                if (CUB) {
+                    const bool ok = !left && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
+                    const double u = xq - x0, t = u * RDX[jj], omt = 1.0 - t;
+                    const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
+                    const double w1 = t * t * (3.0 - 2.0 * t);
+                    const double w2 = u * omt * omt;
+                    const double w3 = u * t * (t - 1.0);
+                    constexpr int LA = 3;
+                    double g0[4], g1[4], g2[4], g3[4];
+#pragma unroll
+                    for (int r = 0; r < LA; ++r) {
+                        g0[r] = Y[r * RS + o0]; g1[r] = Y[r * RS + o1]; g2[r] = S[r * RS + o0]; g3[r] = S[r * RS + o1];
+                    }
+#pragma unroll
+                    for (int r = 0; r < DT; ++r) {
+                        if (r + LA < DT) {
+                            const int nn = r + LA;
+                            g0[nn & 3] = Y[nn * RS + o0]; g1[nn & 3] = Y[nn * RS + o1];
+                            g2[nn & 3] = S[nn * RS + o0]; g3[nn & 3] = S[nn * RS + o1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        z[r] = w0 * g0[r & 3] + w1 * g1[r & 3] + w2 * g2[r & 3] + w3 * g3[r & 3];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    const bool right = j >= n - 1;
+                    const bool hold = right && (METHOD == IVS_LINEAR || xq == xl);
+                    const double dx = x1 - x0, rdx = refined_rcp(dx);
+                    bool slow = !div_safe(dx);
+                    constexpr int LA = 6;
+                    double g0[8], g1[8];
+#pragma unroll
+                    for (int r = 0; r < LA; ++r) { g0[r] = Y[r * RS + o0]; g1[r] = Y[r * RS + o1]; }
+#pragma unroll
+                    for (int r = 0; r < DT; ++r) {
+                        if (r + LA < DT) { const int nn = r + LA; g0[nn & 7] = Y[nn * RS + o0]; g1[nn & 7] = Y[nn * RS + o1]; }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const double y0 = g0[r & 7], y1 = g1[r & 7];
+                        double v = lerp_fast(xq, x0, y0, y1, dx, rdx, slow);
+                        if (right) v = hold ? y1 : nanv;
+                        if (left) v = nanv;
+                        z[r] = v;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (__builtin_expect(__ballot(slow && !right && !left) != 0ull, 0)) {
+                        if (slow && !right && !left) {
+#pragma unroll
+                            for (int r = 0; r < DT; ++r) z[r] = lerp_np(xq, x0, Y[r * RS + o0], x1, Y[r * RS + o1]);
+                        }
+                    }
+                }
+                dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, act, mT, mK, nostamp);
+            }
+            if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
+        }
+        b = b_next; n = n_next; koff = koff_next;
+    }
+}
+
+// Dispatch for variable strike counts.  Returns 1 if dispatched (dense var kernel(s) + filtered generic redo pass),
+// 0 if the batch is not covered.
+inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name) {
+    if (p.nT != DT || p.t_stride != 0 || p.tq_stride != 0 || p.mT > D_MAX_MT) return 0;
+    if (p.nK < 4 || p.nK > 128) return 0;
+    if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
+    if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
+    const bool wl = p.mT <= D_WLDS_MAX_MT;
+    const bool need1 = p.k_off ? true : p.nK <= 64;
+    const bool need2 = p.nK > 64;
+    auto grid_for = [&](size_t lds) {
+        int per_cu = (int)((160 * 1024) / lds);
+        per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+        int64_t g = (int64_t)num_cu * per_cu;
+        return g > p.B ? p.B : g;
+    };
+#define IVS_VAR_LAUNCH(M, NKB, LO, HI, TAG)                                                                          \
+    {                                                                                                                \
+        const size_t lds = dense_var_lds_bytes<NKB>(p.mT);                                                           \
+        const int64_t grid = grid_for(lds);                                                                          \
+        static bool attr = false;                                                                                    \
+        if (!attr) {                                                                                                 \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_var_kernel<M, NKB, true>));                      \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_var_kernel<M, NKB, false>));                     \
+            attr = true;                                                                                             \
+        }                                                                                                            \
+        if (wl) hipLaunchKernelGGL((surface_dense_var_kernel<M, NKB, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
+        else hipLaunchKernelGGL((surface_dense_var_kernel<M, NKB, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);     \
+    }
+#define IVS_VAR_CASE(M, NAME)                                                  \
+    case M:                                                                    \
+        if (need1) IVS_VAR_LAUNCH(M, 1, 4, 64, 1)                              \
+        if (need2) IVS_VAR_LAUNCH(M, 2, 65, 128, need1 ? 0 : 1)                \
+        *name = NAME;                                                          \
+        break;
+    switch (p.method) {
+        IVS_VAR_CASE(IVS_LINEAR, "surface_dense_var_kernel<linear>")
+        IVS_VAR_CASE(IVS_CUBIC, "surface_dense_var_kernel<cubic>")
+        IVS_VAR_CASE(IVS_CUBICSPLINE, "surface_dense_var_kernel<cubicspline>")
+        IVS_VAR_CASE(IVS_SLINEAR, "surface_dense_var_kernel<slinear>")
+        default: return 0;
+    }
+#undef IVS_VAR_CASE
+#undef IVS_VAR_LAUNCH
+    if (hipGetLastError() != hipSuccess) return -1;
+    launch_surface_generic<true>(p, num_cu, st);
+    return 1;
+}
+
+}  // namespace ivs

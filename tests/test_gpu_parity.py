@@ -208,3 +208,63 @@ def test_full_size_properties_1M(method):
     outk, _ = engine.surface_batch(d["K"][sub], d["T"], d["sigma"][sub], d["K"][sub].contiguous(), d["T"], method)
     err = float((outk - d["sigma"][sub]).abs().max())
     assert err <= (0.0 if method == "linear" else 1e-12), err
+
+
+@pytest.mark.parametrize("method", list(METHODS))
+@pytest.mark.parametrize("nK", [4, 5, 15, 16, 17, 33, 48, 63, 65, 81, 100, 127, 128])
+def test_dense_var_uniform_strike_counts(method, nK):
+    """Variable-shape dense kernel (4..128 strikes x 16 maturities): every surface against the oracle."""
+    from iv_interpolation_amd import synth
+    d = synth.numpy_batch(300, nK, 16, seed=synth.BASE_SEED + nK)
+    Kq, Tq = synth.query_grids(64, 16)
+    got, st, kern = _run(d, Kq, Tq, method)
+    assert "dense_var" in kern, kern
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    assert np.array_equal(st, rst)
+    close(got, ref, method, f"var nK={nK} {method}")
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_dense_var_ragged_with_nan_and_tiny_surfaces(method):
+    """Ragged batch mixing both size classes, surfaces with NaN quotes and surfaces below 4 strikes (generic redo)."""
+    from iv_interpolation_amd import engine, synth
+    d = synth.numpy_ragged_batch(600, 16, 2, 128, seed=synth.BASE_SEED + 55)
+    sig = d["sigma"].copy()
+    r = np.random.default_rng(5)
+    for b in r.choice(600, 40, replace=False):                      # poke NaNs into 40 surfaces
+        a = 16 * d["k_off"][b]; e = 16 * d["k_off"][b + 1]
+        sig[a + r.integers(0, e - a)] = np.nan
+    Kq, Tq = synth.query_grids(64, 16)
+    out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(sig), dev(Kq), dev(Tq), method,
+                                   k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=16)
+    assert "dense_var" in engine.last_kernel()
+    ref, rst = O.surface_batch(d["K"], d["T"], sig, Kq, Tq, METHODS[method], k_off=d["k_off"])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    close(out.cpu().numpy(), ref, method, f"ragged+nan {method}")
+
+
+def test_dense_var_config4_grid_and_1M_ragged_properties():
+    import torch
+    from iv_interpolation_amd import engine, synth
+    d = synth.numpy_batch(200, 100, 16, seed=77)
+    Kq, Tq = synth.query_grids(256, 64)
+    got, st, kern = _run(d, Kq, Tq, "cubic")
+    ref, _ = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, O.CUBIC)
+    close(got, ref, "cubic", f"var cfg4 grid [{kern}]")
+    # config 5 at full size: sample vs oracle + affine equivariance
+    B = 1_000_000
+    dr = synth.torch_ragged_batch(B, 16, 8, 128, seed=synth.BASE_SEED)
+    Kq, Tq = synth.query_grids(64, 16)
+    kw = dict(k_off=dr["k_off"], nK_max=dr["nK_max"], n_maturities=16)
+    out, st = engine.surface_batch(dr["K"], dr["T"], dr["sigma"], dev(Kq), dev(Tq), "cubic", **kw)
+    torch.cuda.synchronize()
+    assert int(st.max()) == 0 and not bool(torch.isnan(out).any())
+    koff = dr["k_off"].cpu().numpy()
+    idx = np.arange(0, B, 9973)
+    Kh = dr["K"].cpu().numpy(); sh = dr["sigma"].cpu().numpy()
+    for b in idx:
+        a, e = koff[b], koff[b + 1]
+        r1, _ = O.surface(Kh[a:e], dr["T"].cpu().numpy(), sh[16 * a:16 * e].reshape(16, e - a), Kq, Tq, O.CUBIC)
+        assert np.allclose(out[b].cpu().numpy(), r1, rtol=RTOL, atol=ATOL), b
+    out2, _ = engine.surface_batch(dr["K"], dr["T"], dr["sigma"] * 2.0 + 0.25, dev(Kq), dev(Tq), "cubic", **kw)
+    assert float((out2 - (out * 2.0 + 0.25)).abs().max()) < 1e-11

@@ -10,6 +10,7 @@ python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_dense
 python bench.py --steps 20 --warmup 3 --method linear --no-cpu-baseline > gpurun_out/bench_dense_linear.json 2>gpurun_out/bench_dense_linear.err
 python bench.py --steps 10 --warmup 2 --workload cfg4 --no-cpu-baseline > gpurun_out/bench_dense_cfg4.json 2>gpurun_out/bench_dense_cfg4.err
 python bench.py --steps 10 --warmup 2 --workload cfg4 --method linear --no-cpu-baseline > gpurun_out/bench_dense_cfg4lin.json 2>gpurun_out/bench_dense_cfg4lin.err
+python bench.py --steps 5 --warmup 1 --workload cfg5 --no-cpu-baseline > gpurun_out/bench_dense_cfg5.json 2>gpurun_out/bench_dense_cfg5.err
 python - <<'PY'
 import json,glob
 for f in ("gpurun_out/stamp_cubic.json","gpurun_out/stamp_linear.json"):
