@@ -34,8 +34,14 @@ enum {
     IVS_LINEAR      = 0, /* 'linear','index','values': np.interp; NaN left of the first knot, hold-last on the right */
     IVS_CUBIC       = 1, /* 'cubic': interp1d(kind=3) = not-a-knot spline; NaN outside the hull; needs >= 4 knots */
     IVS_CUBICSPLINE = 2, /* 'cubicspline': CubicSpline(not-a-knot); 2 knots = line, 3 = parabola; NaN left, extrapolates right */
-    IVS_SLINEAR     = 3  /* 'slinear': interp1d(kind=1); NaN outside the hull; needs >= 2 knots */
+    IVS_SLINEAR     = 3, /* 'slinear': interp1d(kind=1); NaN outside the hull; needs >= 2 knots */
+    IVS_NEAREST     = 4, /* 'nearest': interp1d nearest, ties to the left knot; NaN outside the hull; >= 1 knot */
+    IVS_ZERO        = 5, /* 'zero': order-0 spline = left knot's value; NaN outside the hull; >= 1 knot */
+    IVS_PCHIP       = 6, /* 'pchip': PchipInterpolator; NaN left, extrapolates right; >= 2 knots */
+    IVS_AKIMA       = 7, /* 'akima': Akima1DInterpolator; NaN outside the hull; >= 3 knots (scipy's 2-knot case is undefined) */
+    IVS_FROM_DERIVATIVES = 8 /* 'from_derivatives' / 'piecewise_polynomial': BPoly on values = Bernstein-form lines; NaN outside; >= 2 */
 };
+/* methods 0-3 run on the dense fast kernels; 4-8 on the generic surface kernel and the 1-D kernels */
 
 /* return codes */
 enum {

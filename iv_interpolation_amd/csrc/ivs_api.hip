@@ -36,7 +36,7 @@ int check_launch(const char* what) {
     return IVS_OK;
 }
 
-bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_SLINEAR; }
+bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_FROM_DERIVATIVES; }
 
 int g_num_cu = 0;
 int num_cu() {

@@ -134,9 +134,124 @@ struct CView {
     __device__ __forceinline__ double operator()(int i) const { return p[i * stride]; }
 };
 
-__device__ __forceinline__ bool method_is_cubic(int m) { return m == IVS_CUBIC || m == IVS_CUBICSPLINE; }
+// methods that evaluate a C1 piecewise cubic from knot slopes (not-a-knot solve, pchip or akima local rules)
+__device__ __forceinline__ bool method_is_cubic(int m) {
+    return m == IVS_CUBIC || m == IVS_CUBICSPLINE || m == IVS_PCHIP || m == IVS_AKIMA;
+}
+__device__ __forceinline__ bool method_extrapolates_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }
 __device__ __forceinline__ int method_min_knots(int m) {
-    return m == IVS_LINEAR ? 0 : (m == IVS_CUBIC ? 4 : 2);
+    switch (m) {
+        case IVS_LINEAR: return 0;
+        case IVS_CUBIC: return 4;
+        case IVS_NEAREST: case IVS_ZERO: return 1;
+        case IVS_AKIMA: return 3;
+        default: return 2;
+    }
+}
+
+// ---- step / Bernstein evaluators (oracle nearest_eval, zero_eval, bpoly_linear_eval)
+template <class XA, class YA>
+__device__ __forceinline__ double eval_nearest(const XA& x, const YA& y, int n, double xq) {
+    if (!(xq >= x(0) && xq <= x(n - 1))) return qnan();
+    int lo = 0, hi = n - 1;                    // first i with x_i/2 + x_{i+1}/2 >= xq (searchsorted side='left')
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (x(mid) / 2.0 + x(mid + 1) / 2.0 < xq) lo = mid + 1; else hi = mid;
+    }
+    return y(lo);
+}
+template <class XA, class YA>
+__device__ __forceinline__ double eval_zero(const XA& x, const YA& y, int n, int j, double xq) {
+    if (j < 0 || !(xq <= x(n - 1))) return qnan();
+    return y(j > n - 1 ? n - 1 : j);
+}
+template <class XA, class YA>
+__device__ __forceinline__ double eval_bpoly_linear(const XA& x, const YA& y, int n, int j, double xq) {
+#pragma clang fp contract(off)
+    if (j < 0 || !(xq <= x(n - 1))) return qnan();
+    const int jj = j > n - 2 ? n - 2 : j;
+    const double x0 = x(jj);
+    const double s = (xq - x0) / (x(jj + 1) - x0);
+    const double a = y(jj) * (1.0 - s), b = y(jj + 1) * s;
+    return a + b;
+}
+
+__device__ __forceinline__ double sgn(double v) { return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
+
+// PchipInterpolator._find_derivatives + _edge_case (scipy _cubic.py:248-309), one thread per system, n >= 2
+template <class XA, class YA, class SW>
+__device__ __forceinline__ void pchip_slopes(const XA& x, const YA& y, SW& s, int n) {
+    if (n == 2) {
+        const double mk = (y(1) - y(0)) / (x(1) - x(0));
+        s.set(0, mk); s.set(1, mk);
+        return;
+    }
+    auto edge = [](double h0, double h1, double m0, double m1) {
+        const double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+        if (sgn(d) != sgn(m0)) return 0.0;
+        if (sgn(m0) != sgn(m1) && __builtin_fabs(d) > 3.0 * __builtin_fabs(m0)) return 3.0 * m0;
+        return d;
+    };
+    double hp = x(1) - x(0), mp = (y(1) - y(0)) / hp;          // h_{k-1}, m_{k-1}
+    double h0 = hp, m0 = mp;
+    for (int k = 1; k <= n - 2; ++k) {
+        const double hk = x(k + 1) - x(k), mk = (y(k + 1) - y(k)) / hk;
+        if (k == 1) s.set(0, edge(h0, hk, m0, mk));
+        const bool cond = sgn(mk) != sgn(mp) || mk == 0.0 || mp == 0.0;
+        const double w1 = 2.0 * hk + hp, w2 = hk + 2.0 * hp;
+        const double whmean = (w1 / mp + w2 / mk) / (w1 + w2);
+        s.set(k, cond ? 0.0 : 1.0 / whmean);
+        if (k == n - 2) s.set(n - 1, edge(hk, hp, mk, mp));
+        hp = hk; mp = mk;
+    }
+}
+
+// Akima1DInterpolator slopes (scipy _cubic.py:510-541), one thread per system, n >= 3
+template <class XA, class YA, class SW>
+__device__ __forceinline__ void akima_slopes(const XA& x, const YA& y, SW& s, int n) {
+    auto m_in = [&](int k) { return (y(k + 1) - y(k)) / (x(k + 1) - x(k)); };       // 0 <= k <= n-2
+    auto m_ext = [&](int k) -> double {                                             // -2 <= k <= n
+        if (k >= 0 && k <= n - 2) return m_in(k);
+        if (k == -1) return 2.0 * m_in(0) - m_in(1);
+        if (k == -2) { const double a = 2.0 * m_in(0) - m_in(1); return 2.0 * a - m_in(0); }
+        if (k == n - 1) return 2.0 * m_in(n - 2) - m_in(n - 3);
+        const double a = 2.0 * m_in(n - 2) - m_in(n - 3);
+        return 2.0 * a - m_in(n - 2);
+    };
+    double fmax = -__builtin_inf();
+    for (int i = 0; i < n; ++i) {
+        const double f1 = __builtin_fabs(m_ext(i + 1) - m_ext(i)), f2 = __builtin_fabs(m_ext(i - 1) - m_ext(i - 2));
+        const double f12 = f1 + f2;
+        if (f12 > fmax) fmax = f12;
+    }
+    for (int i = 0; i < n; ++i) {
+        const double ma = m_ext(i - 2), mb = m_ext(i - 1), mc = m_ext(i), md = m_ext(i + 1);
+        const double f1 = __builtin_fabs(md - mc), f2 = __builtin_fabs(mb - ma), f12 = f1 + f2;
+        double t = 0.5 * (md + ma);
+        if (f12 > 1e-9 * fmax) t = (f1 * mb + f2 * mc) / f12;
+        s.set(i, t);
+    }
+}
+
+// knot slopes of the method's interpolant (needs n >= method_min_knots and n >= 2)
+template <class XA, class YA, class SW, class CW>
+__device__ __forceinline__ void method_slopes(int method, const XA& x, const YA& y, SW& s, CW& scratch, int n) {
+    if (method == IVS_PCHIP) pchip_slopes(x, y, s, n);
+    else if (method == IVS_AKIMA) akima_slopes(x, y, s, n);
+    else nak_slopes(x, y, s, scratch, n);
+}
+
+// one evaluation of any method on n valid knots (n >= 1 and n >= method_min_knots), j = find_interval(x, n, xq)
+template <class XA, class YA, class SA>
+__device__ __forceinline__ double eval_method(int method, const XA& x, const YA& y, const SA& s, int n, int j, double xq) {
+    switch (method) {
+        case IVS_LINEAR: return eval_linear(x, y, n, j, xq, true);
+        case IVS_SLINEAR: return eval_linear(x, y, n, j, xq, false);
+        case IVS_NEAREST: return eval_nearest(x, y, n, xq);
+        case IVS_ZERO: return eval_zero(x, y, n, j, xq);
+        case IVS_FROM_DERIVATIVES: return eval_bpoly_linear(x, y, n, j, xq);
+        default: return eval_cubic(x, y, s, n, j, xq, method_extrapolates_right(method));
+    }
 }
 
 }  // namespace ivs

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p)
         if (method_is_cubic(p.method) && base >= minkn && base >= 2) {
             CView xv{wx, 1}, yv{wy, 1};
             View sv{p.ws + (int64_t)c * p.total_knots + a, 1}, cv{p.wcp + (int64_t)c * p.total_knots + a, 1};
-            nak_slopes(xv, yv, sv, cv, (int)base);
+            method_slopes(p.method, xv, yv, sv, cv, (int)base);
         }
     }
 }
@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
     const int64_t a = p.knot_off[s];
     const double xq = p.xq ? p.xq[g] : (double)(g - p.q_off[s]);
     const int method = p.method;
-    const bool cubic = method_is_cubic(method);
     const int minkn = method_min_knots(method);
     for (int c = 0; c < p.C; ++c) {
         int n = p.wn[s * p.C + c];
@@ -87,12 +86,8 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
         if (n > 0 && n >= minkn) {
             CView x{p.wx + (int64_t)c * p.total_knots + a, 1}, y{p.wy + (int64_t)c * p.total_knots + a, 1};
             int j = find_interval(x, n, xq);
-            if (cubic) {
-                CView sl{p.ws + (int64_t)c * p.total_knots + a, 1};
-                r = eval_cubic(x, y, sl, n, j, xq, method == IVS_CUBICSPLINE);
-            } else {
-                r = eval_linear(x, y, n, j, xq, method == IVS_LINEAR);
-            }
+            CView sl{p.ws + (int64_t)c * p.total_knots + a, 1};
+            r = eval_method(method, x, y, sl, n, j, xq);
         }
         p.out[c * p.out_stride + g] = r;
     }

@@ -52,8 +52,6 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
     const int nT = p.nT, nKmax = p.nK, LK = nKmax + 1;
     const int method = p.method;
     const bool cubic = method_is_cubic(method);
-    const bool hold = method == IVS_LINEAR;
-    const bool extrap = method == IVS_CUBICSPLINE;
     const int minkn = method_min_knots(method);
 
     double* Ksh = reinterpret_cast<double*>(smem);
@@ -118,7 +116,7 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
             if (n >= minkn && n >= 2) {
                 CView x{xs + lane * LK, 1}, y{ys + lane * LK, 1};
                 View s{ss + lane * LK, 1}, c{cps + lane * LK, 1};
-                nak_slopes(x, y, s, c, n);
+                method_slopes(method, x, y, s, c, n);
             }
         }
         __syncthreads();
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
                 } else if (n > 0) {
                     CView x{xs + t * LK, 1}, y{ys + t * LK, 1}, s{ss + t * LK, 1};
                     int j = (n == nKb) ? jfull : find_interval(x, n, xq);
-                    z = cubic ? eval_cubic(x, y, s, n, j, xq, extrap) : eval_linear(x, y, n, j, xq, hold);
+                    z = eval_method(method, x, y, s, n, j, xq);
                 }
                 if (!__builtin_isnan(z)) {
                     cz[cn * 64 + lane] = z;
@@ -153,14 +151,14 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
             bool few = cn > 0 && cn < minkn;
             if (few && active) st |= IVS_ST_TOO_FEW_KNOTS;
             bool solvable = cn > 0 && !few;
-            if (cubic && solvable && cn >= 2) nak_slopes(cx, cy, csv, ccp, cn);
+            if (cubic && solvable && cn >= 2) method_slopes(method, cx, cy, csv, ccp, cn);
             for (int tq = 0; tq < p.mT; ++tq) {
                 double r = qnan();
                 if (solvable) {
                     double x = Tqb[tq];
                     int j = find_interval(cx, cn, x);
                     CView csr{cs + lane, 64};
-                    r = cubic ? eval_cubic(cx, cy, csr, cn, j, x, extrap) : eval_linear(cx, cy, cn, j, x, hold);
+                    r = eval_method(method, cx, cy, csr, cn, j, x);
                 }
                 if (active) outb[(int64_t)tq * p.mK + q] = r;
             }

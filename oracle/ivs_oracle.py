@@ -40,10 +40,19 @@ CUBIC = 1        # pandas 'cubic'      (interp1d kind=3: not-a-knot, NaN outside
 CUBICSPLINE = 2  # pandas 'cubicspline' (CubicSpline not-a-knot: n==2 line, n==3 parabola,
                  #                       leading NaN, trailing extrapolated)
 SLINEAR = 3      # pandas 'slinear'    (interp1d linear: np.interp inside, NaN outside hull)
+NEAREST = 4      # pandas 'nearest'    (interp1d nearest: ties go to the left knot, NaN outside hull)
+ZERO = 5         # pandas 'zero'       (interp1d kind=0: left knot's value, NaN outside hull)
+PCHIP = 6        # pandas 'pchip'      (PchipInterpolator: leading NaN, trailing extrapolated)
+AKIMA = 7        # pandas 'akima'      (Akima1DInterpolator: NaN outside hull; >= 3 knots, scipy's n == 2 reads
+                 #                       uninitialised memory)
+FROM_DERIVATIVES = 8   # pandas 'from_derivatives' / 'piecewise_polynomial' (BPoly, values only = linear in
+                       #                       Bernstein form, NaN outside hull)
 
 METHOD_CODES = {
     "linear": LINEAR, "index": LINEAR, "values": LINEAR,
     "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
+    "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
+    "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES,
 }
 
 # status codes shared with include/ivs.h
@@ -53,7 +62,8 @@ ST_TOO_FEW_KNOTS = 1   # the reference raises inside scipy -> interpolate_symbol
 
 def min_knots(method: int) -> int:
     """Fewest valid knots the reference accepts before scipy raises."""
-    return {LINEAR: 0, CUBIC: 4, CUBICSPLINE: 2, SLINEAR: 2}[method]
+    return {LINEAR: 0, CUBIC: 4, CUBICSPLINE: 2, SLINEAR: 2, NEAREST: 1, ZERO: 1, PCHIP: 2, AKIMA: 3,
+            FROM_DERIVATIVES: 2}[method]
 
 
 # --------------------------------------------------------------------------- linear
@@ -172,6 +182,87 @@ def hermite_eval(xv, yv, s, xq, *, extrapolate_right: bool):
     return np.where(ok, r, np.nan)
 
 
+# --------------------------------------------------------------------------- local-slope methods / step methods
+def pchip_slopes(x, y):
+    """PchipInterpolator._find_derivatives (scipy _cubic.py:263-309) + _edge_case (:248-260)."""
+    x = np.asarray(x, np.float64); y = np.asarray(y, np.float64)
+    n = x.size
+    hk = x[1:] - x[:-1]
+    mk = (y[1:] - y[:-1]) / hk
+    if n == 2:
+        return np.array([mk[0], mk[0]])
+    smk = np.sign(mk)
+    cond = (smk[1:] != smk[:-1]) | (mk[1:] == 0) | (mk[:-1] == 0)
+    w1 = 2 * hk[1:] + hk[:-1]
+    w2 = hk[1:] + 2 * hk[:-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        whmean = (w1 / mk[:-1] + w2 / mk[1:]) / (w1 + w2)
+    dk = np.zeros(n)
+    dk[1:-1] = np.where(cond, 0.0, 1.0 / whmean)
+
+    def edge(h0, h1, m0, m1):
+        d = ((2 * h0 + h1) * m0 - h0 * m1) / (h0 + h1)
+        if np.sign(d) != np.sign(m0):
+            return 0.0
+        if np.sign(m0) != np.sign(m1) and abs(d) > 3.0 * abs(m0):
+            return 3.0 * m0
+        return d
+    dk[0] = edge(hk[0], hk[1], mk[0], mk[1])
+    dk[-1] = edge(hk[-1], hk[-2], mk[-1], mk[-2])
+    return dk
+
+
+def akima_slopes(x, y):
+    """Akima1DInterpolator.__init__ (scipy _cubic.py:510-541), method='akima'.  n >= 3."""
+    x = np.asarray(x, np.float64); y = np.asarray(y, np.float64)
+    n = x.size
+    m = np.empty(n + 3)
+    m[2:-2] = np.diff(y) / np.diff(x)
+    m[1] = 2.0 * m[2] - m[3]
+    m[0] = 2.0 * m[1] - m[2]
+    m[-2] = 2.0 * m[-3] - m[-4]
+    m[-1] = 2.0 * m[-2] - m[-3]
+    t = 0.5 * (m[3:] + m[:-3])
+    dm = np.abs(np.diff(m))
+    f1 = dm[2:]; f2 = dm[:-2]
+    f12 = f1 + f2
+    ind = f12 > 1e-9 * np.max(f12, initial=-np.inf)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tt = (f1 * m[1:-2] + f2 * m[2:-1]) / f12
+    return np.where(ind, tt, t)
+
+
+def nearest_eval(xv, yv, xq):
+    """interp1d kind='nearest' (scipy _interpolate.py:327-328, 486-501): x_bds = x/2 + x/2 shifted, ties to the left."""
+    xv = np.asarray(xv, np.float64); xq = np.asarray(xq, np.float64)
+    n = xv.size
+    h = xv / 2.0
+    bds = h[1:] + h[:-1]
+    idx = np.clip(np.searchsorted(bds, xq, side="left"), 0, n - 1)
+    out = np.asarray(yv, np.float64)[idx]
+    return np.where((xq >= xv[0]) & (xq <= xv[-1]), out, np.nan)
+
+
+def zero_eval(xv, yv, xq):
+    """interp1d kind='zero' (order-0 spline): the left knot's value on [x_j, x_j+1), y[-1] at the last knot."""
+    xv = np.asarray(xv, np.float64); xq = np.asarray(xq, np.float64)
+    j = _interval(xv, xq)
+    out = np.asarray(yv, np.float64)[np.clip(j, 0, xv.size - 1)]
+    return np.where((j >= 0) & (xq <= xv[-1]), out, np.nan)
+
+
+def bpoly_linear_eval(xv, yv, xq):
+    """BPoly.from_derivatives with function values only (pandas 'from_derivatives'): degree-1 Bernstein form
+    c0*(1-s) + c1*s, s = (x - xa)/(xb - xa) (scipy _ppoly.pyx evaluate_bpoly1, k == 1); NaN outside the hull."""
+    xv = np.asarray(xv, np.float64); yv = np.asarray(yv, np.float64); xq = np.asarray(xq, np.float64)
+    n = xv.size
+    j = _interval(xv, xq)
+    jj = np.clip(j, 0, n - 2)
+    s = (xq - xv[jj]) / (xv[jj + 1] - xv[jj])
+    r = yv[jj] * (1.0 - s) + yv[jj + 1] * s
+    return np.where((j >= 0) & (xq <= xv[-1]), r, np.nan)
+
+
 # --------------------------------------------------------------------------- 1-D operator
 def interp1d(xk, yk, xq, method: int):
     """One masked-knot 1-D interpolation (one channel of core.py:58-61, generalised to
@@ -194,6 +285,16 @@ def interp1d(xk, yk, xq, method: int):
         return lerp_eval(xv, yv, xq, right_hold=True), ST_OK
     if method == SLINEAR:
         return lerp_eval(xv, yv, xq, right_hold=False), ST_OK
+    if method == NEAREST:
+        return nearest_eval(xv, yv, xq), ST_OK
+    if method == ZERO:
+        return zero_eval(xv, yv, xq), ST_OK
+    if method == FROM_DERIVATIVES:
+        return bpoly_linear_eval(xv, yv, xq), ST_OK
+    if method == PCHIP:
+        return hermite_eval(xv, yv, pchip_slopes(xv, yv), xq, extrapolate_right=True), ST_OK
+    if method == AKIMA:
+        return hermite_eval(xv, yv, akima_slopes(xv, yv), xq, extrapolate_right=False), ST_OK
     s = nak_slopes(xv, yv)
     return hermite_eval(xv, yv, s, xq, extrapolate_right=(method == CUBICSPLINE)), ST_OK
 
@@ -325,7 +426,7 @@ def surface_batch(K, T, sigma, Kq, Tq, method: int, k_off=None):
     if k_off is None:
         K = np.asarray(K, np.float64); sigma = np.asarray(sigma, np.float64)
         B, nT, nK = sigma.shape
-        dense = (not np.isnan(sigma).any()) and nK >= 4 and nT >= 4
+        dense = (not np.isnan(sigma).any()) and nK >= 4 and nT >= 4 and method <= SLINEAR
         if dense:
             Tb = np.broadcast_to(T, (B, nT)) if T.ndim == 1 else T
             Z = _dense_pass(K, sigma, Kq, method)                       # [B, nT, mK]

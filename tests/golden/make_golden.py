@@ -147,6 +147,19 @@ df = lattice_frame(np.arange(8) * 10, 120); df.loc[3:, "iv"] = np.nan
 for m in ("cubic", "cubicspline", "linear"):
     add(f"g9_chan_few3_{m}", df.copy(), m, 2)
 
+# further pandas methods (appended after the original cases so their vectors stay byte-identical)
+EXTRA = ("nearest", "zero", "pchip", "akima", "from_derivatives", "piecewise_polynomial")
+for m in EXTRA:
+    add(f"x1_{m}", frame(12, 1), m)
+    dfx = frame(14, 5)
+    dfx.loc[4:6, "iv"] = np.nan; dfx.loc[0:1, "underlying_price"] = np.nan; dfx.loc[12:13, "time_to_maturity"] = np.nan
+    add(f"x5_nan_{m}", dfx, m)
+    add(f"x8_64to256_{m}", lattice_frame(p64, 80), m, 2)
+    for n in (2, 3, 4):
+        add(f"x9_few{n}_{m}", lattice_frame(np.arange(n) * 20, 99 + n), m, 2)
+    dfc = lattice_frame(np.arange(8) * 10, 120); dfc.loc[1:, "iv"] = np.nan
+    add(f"x9_chan_one_knot_{m}", dfc, m, 2)
+
 # seeded fuzz
 rf = np.random.default_rng(20230320)
 for k in range(40):
@@ -220,6 +233,7 @@ def main():
             return None
         return r.loc[xq].to_numpy()
 
+    ALL_METHODS = ("linear", "cubic", "cubicspline", "slinear", "nearest", "zero", "pchip", "akima", "from_derivatives")
     r1 = np.random.default_rng(11)
     real = {}
     k = 0
@@ -236,7 +250,7 @@ def main():
             if n > 4:
                 xq[m // 3] = xk[n // 2]; xq = np.sort(xq)      # one exact knot hit
             real[f"c{k}/xk"] = xk; real[f"c{k}/yk"] = yk; real[f"c{k}/xq"] = xq
-            for meth in ("linear", "cubic", "cubicspline", "slinear"):
+            for meth in ALL_METHODS:
                 v = pandas_1d(xk, yk, xq, meth)
                 real[f"c{k}/{meth}"] = np.array([]) if v is None else v
                 real[f"c{k}/{meth}_raised"] = np.array(v is None)
@@ -266,7 +280,7 @@ def main():
         Kq = S * np.linspace(0.72, 1.28, mK)
         Tq = np.geomspace(2 / 365.0, min(1.4, T[-1]), mT)
         surf[f"s{k}/K"] = K; surf[f"s{k}/T"] = T; surf[f"s{k}/sigma"] = sig; surf[f"s{k}/Kq"] = Kq; surf[f"s{k}/Tq"] = Tq
-        for meth in ("linear", "cubic", "cubicspline", "slinear"):
+        for meth in ALL_METHODS:
             raised = False
             Z = np.full((nT, mK), np.nan)
             for t in range(nT):

@@ -32,8 +32,12 @@ class SymbolCases:
         self.arrs = np.load(os.path.join(GOLDEN, "symbol_cases.npz"))
         self.cases = {c["name"]: c for c in self.manifest["cases"]}
 
+    # scipy 1.15.3's Akima1DInterpolator with exactly 2 knots reads an uninitialised slope (m[3] of np.empty,
+    # _cubic.py:511-516): the reference's output for it is garbage that changes from run to run, so it pins nothing.
+    UNDEFINED_IN_REFERENCE = {"x9_few2_akima"}
+
     def names(self):
-        return list(self.cases)
+        return [n for n in self.cases if n not in self.UNDEFINED_IN_REFERENCE]
 
     def input(self, name):
         c = self.cases[name]
