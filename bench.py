@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--method", default="cubic", choices=["linear", "cubic", "cubicspline", "slinear"])
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1_000_000, help="surfaces per GPU (weak scaling)")
+    ap.add_argument("--nk", type=int, default=0, help="override the strike count of a uniform workload (variable-shape kernel)")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=256, help="surfaces compared with the oracle after the timed region")
@@ -126,6 +127,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     nK, nT, mK, mT, ragged, desc = WORKLOADS[a.workload]
+    if a.nk and not ragged:
+        nK = a.nk
+        desc = desc.replace("64 strikes", f"{nK} strikes").replace("(64x16)", f"({nK}x16)")
     B = a.batch
     seed = synth.BASE_SEED + rank
     Kq_h, Tq_h = synth.query_grids(mK, mT, nT)

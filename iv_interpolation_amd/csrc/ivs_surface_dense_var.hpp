@@ -19,8 +19,8 @@ constexpr int DPP_QUAD_BCAST0 = 0x00, DPP_QUAD_BCAST3 = 0xFF;   // quad_perm:[0,
 
 template <int NKB>
 __host__ __device__ inline size_t dense_var_lds_bytes(int mT) {
-    // Y, S planes [16][NKB*72]; Ksh [NKB*64 + 8]; RDX [NKB*64]; TT [16][4]; W [16][4] when mT <= 16
-    return (size_t)(2 * DT * NKB * 72 + NKB * 64 + 8 + NKB * 64 + 64 + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
+    // Y, S planes [16][NKB*72]; Ksh [NKB*64]; RDX [NKB*64]; TT [16][4]; W [16][4] when mT <= 16
+    return (size_t)(2 * DT * NKB * 72 + NKB * 64 + NKB * 64 + 64 + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
 }
 
 // Factor tables for n knots (run time) spread over NKB blocks of 64 lanes.  Tables are written at d_sl(i), i < n.
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
     const int mT = p.mT, mK = p.mK;
     double* Y = reinterpret_cast<double*>(smem);
     double* S = Y + DT * RS;
-    double* Ksh = S + DT * RS;             // KCAP + 8 (the tail stays +inf)
-    double* RDX = Ksh + KCAP + 8;
+    double* Ksh = S + DT * RS;             // KCAP entries; strikes beyond n are +inf (searches never index past KCAP-1)
+    double* RDX = Ksh + KCAP;
     double* TT = RDX + KCAP;
     double* W = TT + 64;
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
@@ -232,7 +232,6 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
 
     TqTables tt;
     dense_t_phase<METHOD, WLDS>(p.T, p.Tq, mT, lane, Y, TT, W, tt);       // shared T/Tq: once per workgroup
-    if (lane < 8) Ksh[KCAP + lane] = inf;
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
