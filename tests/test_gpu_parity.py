@@ -273,3 +273,40 @@ def test_dense_var_config4_grid_and_1M_ragged_properties():
         assert np.allclose(out[b].cpu().numpy(), r1, rtol=RTOL, atol=ATOL), b
     out2, _ = engine.surface_batch(dr["K"], dr["T"], dr["sigma"] * 2.0 + 0.25, dev(Kq), dev(Tq), "cubic", **kw)
     assert float((out2 - (out * 2.0 + 0.25)).abs().max()) < 1e-11
+
+
+@pytest.mark.parametrize("method", DENSE_METHODS)
+def test_dense_kernels_edge_shapes_and_grids(method):
+    """Dense and variable-shape kernels on awkward sizes: tiny batches, output grids that are not multiples of 64,
+    1 / 17 / 64 / 65 query maturities, queries outside the hull on both sides, unsorted Kq (fine) and unsorted Tq
+    (generic redo), shared strikes."""
+    from iv_interpolation_amd import engine, synth
+    r = np.random.default_rng(123)
+    T = synth.tenors(16)
+    cases = [
+        # (B, nK, mK, mT, kq_lo, kq_hi, tq_lo, tq_hi, shared_K, shuffle_kq, shuffle_tq)
+        (1, 64, 64, 16, .72, 1.28, 2 / 365, 1.4, False, False, False),
+        (3, 64, 70, 17, .60, 1.40, .5 / 365, 2.0, False, False, False),
+        (5, 64, 1, 1, .90, .90, .3, .3, False, False, False),
+        (300, 64, 63, 64, .72, 1.28, 2 / 365, 1.4, True, False, False),
+        (300, 64, 129, 65, .65, 1.35, 1 / 365, 1.6, False, True, False),
+        (40, 64, 64, 16, .72, 1.28, 2 / 365, 1.4, False, False, True),
+        (7, 40, 33, 5, .60, 1.40, .5 / 365, 2.0, False, True, False),
+        (9, 100, 200, 30, .72, 1.28, 2 / 365, 1.4, True, False, False),
+    ]
+    for (B, nK, mK, mT, klo, khi, tlo, thi, shared_K, sh_kq, sh_tq) in cases:
+        d = synth.numpy_batch(B, nK, 16, seed=int(r.integers(1 << 30)))
+        K = d["K"][0] if shared_K else d["K"]
+        Kq = np.linspace(klo, khi, mK); Tq = np.linspace(tlo, thi, mT)
+        Kq[mK // 2] = (d["K"][0] if shared_K else d["K"][0])[nK // 3]       # an exact knot hit
+        if mT > 2:
+            Tq[mT // 2] = T[5]
+        if sh_kq:
+            Kq = r.permutation(Kq)
+        if sh_tq:
+            Tq = r.permutation(Tq)
+        out, st = engine.surface_batch(dev(K), dev(T), dev(d["sigma"]), dev(Kq), dev(Tq), method)
+        Kfull = np.tile(K, (B, 1)) if shared_K else K
+        ref, rst = O.surface_batch(Kfull, T, d["sigma"], Kq, Tq, METHODS[method])
+        assert np.array_equal(st.cpu().numpy(), rst), (B, nK, mK, mT)
+        close(out.cpu().numpy(), ref, method, f"edge B={B} nK={nK} mK={mK} mT={mT} [{engine.last_kernel()}]")
