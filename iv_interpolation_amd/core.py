@@ -123,6 +123,129 @@ class IVInterpolator:
                 results[i] = None
         return results
 
+    def interpolate_frame(self, data: pd.DataFrame) -> pd.DataFrame:
+        """Columnar ingest/egress: ALL symbols of one long frame -- what the reference reads
+        with ``SELECT ... FROM trading_tickers ORDER BY symbol, date`` -- in one pass of vectorised NumPy bookkeeping
+        and one device round trip, instead of one DataFrame per symbol (batch_processor.py:67-142 loops over symbols,
+        then ``iterrows()`` :166-173).  The result equals
+        ``pd.concat([interpolate_symbol(g) for _, g in data.groupby("symbol", sort=True)], ignore_index=True)``
+        (symbols whose result is ``None`` contribute nothing).  Rows with a null symbol or an unparsable date are ignored."""
+        for c in ["date"] + REQUIRED:
+            if c not in data.columns:
+                raise KeyError(c)
+        if self.method not in METHOD_CODES:
+            raise ValueError(f"method '{self.method}' is not implemented by the MI355X engine")
+        code = METHOD_CODES[self.method]
+        be = self._backend or HipBackend()
+        cols_in = [c for c in data.columns if c != "date"]
+        out_cols = ["date"] + cols_in + (["is_interpolated"] if "is_interpolated" not in cols_in else [])
+        d_idx = pd.DatetimeIndex(pd.to_datetime(data["date"]))
+        tz = d_idx.tz
+        d_ns = d_idx.as_unit("ns").asi8
+        sym_codes, sym_uniques = pd.factorize(data["symbol"], sort=True)
+        ok_row = (sym_codes >= 0) & ~np.asarray(d_idx.isna())
+        rows = np.flatnonzero(ok_row)
+        rows = rows[np.lexsort((d_ns[rows], sym_codes[rows]))]          # by symbol, then date (stable)
+        sc = sym_codes[rows]; dn = d_ns[rows]
+        S_all = len(sym_uniques)
+        empty = pd.DataFrame({c: pd.Series(dtype=(bool if c == "is_interpolated" else data[c].dtype if c in data.columns else "float64"))
+                              for c in out_cols})
+        if len(rows) == 0:
+            return empty
+        start = np.searchsorted(sc, np.arange(S_all), side="left")
+        count = np.searchsorted(sc, np.arange(S_all), side="right") - start
+        present = count > 0
+        first_ns = np.where(present, dn[np.minimum(start, len(dn) - 1)], 0)
+        last_ns = np.where(present, dn[np.minimum(start + count - 1, len(dn) - 1)], 0)
+        span = last_ns - first_ns
+        keep_sym = present & (count >= self.min_points) & (span <= 30 * 24 * 3600 * 1_000_000_000)   # core.py:26-28, 36-39
+        m0 = span // MINUTE_NS + 1
+        keep_sym &= m0 <= 100000                                                                     # core.py:49-51
+        rel = dn - first_ns[sc]
+        on = keep_sym[sc] & (rel % MINUTE_NS == 0)                        # off-lattice rows vanish (R6)
+        ridx = np.flatnonzero(on)
+        if len(ridx) == 0:
+            return empty
+        rsym = sc[ridx]; lat = rel[ridx] // MINUTE_NS
+        # compact symbol numbering over the kept symbols
+        kept = np.flatnonzero(keep_sym)
+        renum = np.full(S_all, -1, np.int64); renum[kept] = np.arange(len(kept))
+        ks = renum[rsym]                                                 # kept-symbol id of every on-lattice source row
+        S = len(kept)
+        q = np.bincount(ks, minlength=S).astype(np.int64)                # on-lattice rows per symbol (>= 1: the first row)
+        src_off = np.concatenate([[0], np.cumsum(q)]).astype(np.int64)
+        newsym = np.ones(len(ridx), bool); newsym[1:] = ks[1:] != ks[:-1]
+        first = newsym.copy(); first[1:] |= lat[1:] != lat[:-1]          # first source row of its lattice point
+        cum_first = np.cumsum(first)
+        u_within = cum_first - (cum_first[src_off[:-1]] - 1)[ks]         # distinct lattice points so far, within the symbol
+        i_within = np.arange(len(ridx)) - src_off[:-1][ks]
+        pos = lat + i_within + 1 - u_within                              # merged-frame position (R7, R8)
+        m0k = m0[kept]
+        M = m0k + (q - u_within[src_off[1:] - 1])
+        q_off = np.concatenate([[0], np.cumsum(M)]).astype(np.int64)
+        total_q = int(q_off[-1])
+        src_rows = rows[ridx]                                            # positions in `data` of the on-lattice rows
+        # ---- channels
+        chan = [data[c].to_numpy(dtype=np.float64, na_value=np.nan)[src_rows] for c in NUMERIC_COLS]
+        nan_cnt = np.stack([np.add.reduceat(np.isnan(v).astype(np.int64), src_off[:-1]) for v in chan], 1) + (M - q)[:, None]
+        needs = (nan_cnt > 0) & (nan_cnt < M[:, None])                   # pandas leaves all-NaN / no-NaN columns alone
+        out, status = be.interp1d_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code)
+        sym_ok = ~((status != ST_OK) & needs).any(1)                     # scipy would raise -> that symbol is None
+        # ---- forward-fill gather index
+        fill_cols = [c for c in FILL_COLS if c in data.columns]
+        src_np = {c: data[c].to_numpy()[src_rows] for c in cols_in}
+        valid = np.stack([(~pd.isna(src_np[c])).astype(np.uint8) for c in fill_cols])
+        fidx = be.ffill_index_batch(pos.astype(np.int64), src_off, valid, q_off, total_q)
+        # ---- assemble the long output
+        sym_of_row = np.repeat(np.arange(S), M)
+        gpos = q_off[:-1][ks] + pos                                      # global output row of every source row
+        nothing_missing = bool((M == q).all())
+        lat_off = np.concatenate([[0], np.cumsum(m0k)])
+        cnt = np.ones(int(lat_off[-1]), np.int64)
+        dup = ~first
+        if dup.any():
+            np.add.at(cnt, lat_off[:-1][ks[dup]] + lat[dup], 1)          # duplicates multiply the timeline row (R7)
+            glat = np.repeat(np.arange(int(lat_off[-1])), cnt)
+        else:
+            glat = np.arange(total_q)
+        lat_in_sym = glat - lat_off[:-1][sym_of_row]
+        date_ns = first_ns[kept][sym_of_row] + lat_in_sym * MINUTE_NS
+        dates = pd.DatetimeIndex(date_ns.view("datetime64[ns]"))
+        if tz is not None:
+            dates = dates.tz_localize("UTC").tz_convert(tz)
+        cols = {"date": dates}
+        raw_idx = None
+        for name in cols_in:
+            v = src_np[name]
+            int_dtype = v.dtype if v.dtype.kind in "iub" else None
+            if name in NUMERIC_COLS:
+                ci = NUMERIC_COLS.index(name)
+                merged = np.full(total_q, np.nan)
+                merged[gpos] = chan[ci]
+                fill = np.isnan(merged) & needs[sym_of_row, ci]
+                merged = np.where(fill, out[ci], merged)
+                if nothing_missing and int_dtype is not None:
+                    merged = merged.astype(int_dtype)
+                elif data[name].dtype == object:
+                    merged = merged.astype(object)
+                cols[name] = merged
+            elif name in fill_cols:
+                cols[name] = _gather(v, fidx[fill_cols.index(name)].astype(np.int64), int_dtype, nothing_missing)
+            else:
+                if raw_idx is None:
+                    raw_idx = np.full(total_q, -1, np.int64)
+                    raw_idx[gpos] = np.arange(len(gpos))
+                cols[name] = _gather(v, raw_idx, int_dtype, nothing_missing)
+        sym_na = pd.isna(cols["symbol"])
+        keep = ~sym_na & sym_ok[sym_of_row]
+        for c in REQUIRED[1:]:
+            keep &= ~pd.isna(cols[c])
+        cols["is_interpolated"] = sym_na
+        res = pd.DataFrame({c: cols[c] for c in out_cols}, copy=False)
+        if not keep.all():
+            res = res[keep].reset_index(drop=True)
+        return res
+
     # ------------------------------------------------------------------ host bookkeeping
     def _prepare(self, symbol_data: pd.DataFrame) -> Optional[_Prepared]:
         if len(symbol_data) < self.min_points:                           # core.py:26-28

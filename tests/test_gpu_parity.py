@@ -310,3 +310,21 @@ def test_dense_kernels_edge_shapes_and_grids(method):
         ref, rst = O.surface_batch(Kfull, T, d["sigma"], Kq, Tq, METHODS[method])
         assert np.array_equal(st.cpu().numpy(), rst), (B, nK, mK, mT)
         close(out.cpu().numpy(), ref, method, f"edge B={B} nK={nK} mK={mK} mT={mT} [{engine.last_kernel()}]")
+
+
+def test_interpolate_frame_on_gpu_equals_per_symbol():
+    import pandas as pd
+    from iv_interpolation_amd import IVInterpolator
+    from iv_interpolation_amd.frame_store import synthetic_symbol
+    frames = [synthetic_symbol(f"s{i:03d}", 30 + i % 20, seed=i) for i in range(40)]
+    frames[3].loc[5:9, "iv"] = np.nan; frames[7].loc[0, "underlying_price"] = np.nan; frames[9] = frames[9].iloc[:5]
+    for method in ("linear", "cubic"):
+        iv = IVInterpolator(method)
+        got = iv.interpolate_frame(pd.concat(frames[::-1], ignore_index=True))
+        exp = pd.concat([r for r in iv.interpolate_batch(frames) if r is not None], ignore_index=True)
+        assert list(got.columns) == list(exp.columns) and len(got) == len(exp)
+        for c in exp.columns:
+            if exp[c].dtype.kind == "f":
+                assert np.array_equal(got[c].to_numpy(), exp[c].to_numpy(), equal_nan=True), (method, c)
+            else:
+                assert (got[c].astype(str) == exp[c].astype(str)).all(), (method, c)

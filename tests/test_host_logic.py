@@ -48,3 +48,53 @@ def test_no_cpu_fallback_without_gpu():
     df = CASES.input("g1_linear")
     with pytest.raises(EngineUnavailable):
         IVInterpolator().interpolate_symbol(df)
+
+
+def _long_frame(names, rename=True):
+    frames = []
+    for i, n in enumerate(names):
+        f = CASES.input(n).copy()
+        if rename and "symbol" in f.columns:
+            f["symbol"] = f["symbol"].where(f["symbol"].isna(), f"sym{i:03d}-" + n)
+        frames.append(f)
+    return frames
+
+
+@pytest.mark.parametrize("method,min_points", [("linear", 2), ("linear", 10), ("cubic", 2), ("pchip", 2)])
+def test_interpolate_frame_equals_concat_of_per_symbol_results(method, min_points):
+    """Columnar path: one long frame with many symbols == concat of the per-symbol results (which are golden-checked)."""
+    full = {"symbol", "date", "iv", "underlying_price", "time_to_maturity", "strike"}
+    names = [n for n in CASES.names() if set(CASES.input(n).columns) == full or n.startswith(("g4_dup", "g3_", "g5_nan", "fuzz"))]
+    # one long frame needs one column set: use the 13-column cases and the 6-column cases separately
+    groups = {}
+    for n in names:
+        groups.setdefault(tuple(CASES.input(n).columns), []).append(n)
+    iv = IVInterpolator(method, min_points, backend=OracleBackend())
+    checked = 0
+    for colset, ns in groups.items():
+        if len(ns) < 3 or "symbol" not in colset:
+            continue
+        frames = _long_frame(ns)
+        # symbols in arbitrary order; rows of one symbol keep their input order (ties between duplicate
+        # timestamps are resolved by input order, as in the per-symbol path)
+        long = pd.concat(frames[::-1], ignore_index=True)
+        got = iv.interpolate_frame(long)
+        per = [iv.interpolate_symbol(f) for f in frames]
+        order = np.argsort([f["symbol"].dropna().iloc[0] for f in frames], kind="stable")
+        exp = [per[i] for i in order if per[i] is not None]
+        if not exp:
+            assert len(got) == 0
+            continue
+        exp = pd.concat(exp, ignore_index=True)
+        assert list(got.columns) == list(exp.columns)
+        assert len(got) == len(exp), (len(got), len(exp))
+        for c in exp.columns:
+            g, e = got[c], exp[c]
+            if e.dtype.kind == "f":
+                assert np.array_equal(g.to_numpy(np.float64), e.to_numpy(np.float64), equal_nan=True), c
+            elif e.dtype == object:
+                assert ((g == e) | (g.isna() & e.isna())).all(), c
+            else:
+                assert (g.to_numpy() == e.to_numpy()).all(), c
+        checked += 1
+    assert checked >= 2

@@ -40,6 +40,13 @@ iv = IVInterpolator(a.method)
 iv.interpolate_batch(frames[:8])
 t0 = time.perf_counter(); out = iv.interpolate_batch(frames); dt = time.perf_counter() - t0
 res["end_to_end_batch"] = {"symbols": a.e2e, "symbols_per_s": a.e2e / dt, "rows_per_s": sum(len(o) for o in out) / dt}
+import pandas as pd
+big = [synthetic_symbol(f"s{i:05d}", n, seed=i) for i in range(2048)]
+long = pd.concat(big, ignore_index=True)
+iv.interpolate_frame(long.iloc[: 64 * n])
+t0 = time.perf_counter(); lf = iv.interpolate_frame(long); dtf = time.perf_counter() - t0
+res["end_to_end_frame"] = {"symbols": 2048, "symbols_per_s": 2048 / dtf, "rows_per_s": len(lf) / dtf,
+                           "note": "one long DataFrame in, one long DataFrame out (interpolate_frame)"}
 t0 = time.perf_counter(); [iv.interpolate_symbol(f) for f in frames[:32]]; dt1 = time.perf_counter() - t0
 res["end_to_end_single"] = {"symbols_per_s": 32 / dt1}
 import ref_symbol

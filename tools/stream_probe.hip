@@ -3,19 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-template <int STORE_W>   // 1: dwordx2 rows of 512 B (as the kernel), 2: dwordx4 (two rows per instruction)
+template <int STORE_W, bool NT = false>   // 1: dwordx2 rows of 512 B (as the kernel), 2: dwordx4 (two rows per instruction); NT: non-temporal hints
 __global__ __launch_bounds__(64) void probe(const double* sig, const double* K, double* out, long B) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     double2 pre[8]; double pk;
     auto pf = [&](long b) { const double2* s2 = (const double2*)(sig + b * 1024);
-        for (int i = 0; i < 8; ++i) pre[i] = s2[i * 64 + lane]; pk = K[b * 64 + lane]; };
+        for (int i = 0; i < 8; ++i) { if (NT) { pre[i].x = __builtin_nontemporal_load(&s2[i * 64 + lane].x); pre[i].y = __builtin_nontemporal_load(&s2[i * 64 + lane].y); } else pre[i] = s2[i * 64 + lane]; } pk = K[b * 64 + lane]; };
     long b = blockIdx.x; if (b < B) pf(b);
     for (; b < B; b += gridDim.x) {
         double2 cur[8]; for (int i = 0; i < 8; ++i) cur[i] = pre[i]; double ck = pk;
         if (b + gridDim.x < B) pf(b + gridDim.x);
         double* ob = out + b * 1024;
-        if (STORE_W == 1) { for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = (r & 1 ? cur[r >> 1].y : cur[r >> 1].x) + ck; }
+        if (STORE_W == 1) { for (int r = 0; r < 16; ++r) { double v = (r & 1 ? cur[r >> 1].y : cur[r >> 1].x) + ck; if (NT) __builtin_nontemporal_store(v, &ob[r * 64 + lane]); else ob[r * 64 + lane] = v; } }
         else { double2* o2 = (double2*)ob; for (int i = 0; i < 8; ++i) { double2 v = cur[i]; v.x += ck; o2[i * 64 + lane] = v; } }
     }
 }
@@ -35,5 +35,8 @@ int main() {
         }
         printf("lds %6d B  wg/CU %2d  store %s : %.3f ms  %.0f GB/s  (%.1f M surfaces/s)\n", lds, per_cu, sw == 1 ? "dwordx2" : "dwordx4", best, bytes / best / 1e6, B / best / 1e3);
     }
+    { int grid = 256 * 8; float best = 1e9;
+      for (int it = 0; it < 6; ++it) { hipEventRecord(e0); probe<1, true><<<grid, 64, 20480>>>(sig, K, out, B); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (it && ms < best) best = ms; }
+      printf("lds  20480 B  wg/CU  8  dwordx2 + NON-TEMPORAL loads/stores : %.3f ms  %.0f GB/s  (%.1f M surfaces/s)\n", best, bytes / best / 1e6, B / best / 1e3); }
     return 0;
 }
