@@ -118,7 +118,7 @@ def main():
     dev_index = local if backend == "nccl" else local % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("IVS_FORCE_DIST") == "1":     # IVS_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
