@@ -531,17 +531,16 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         }
         __syncthreads();
         stamp(0);
-        if (CUB) {
-            dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
-            __syncthreads();
-            stamp(2);
-        }
-
         const double* Kqb = p.Kq + b * p.kq_stride;
         if (!kq_shared) load_xq(Kqb);
         {
             const int64_t bn = b + gridDim.x;
-            if (bn < p.B) prefetch(bn);                    // next surface's loads fly during evaluation + maturity pass
+            if (bn < p.B) prefetch(bn);                    // next surface's loads fly during the whole computation
+        }
+        if (CUB) {
+            dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
+            __syncthreads();
+            stamp(2);
         }
 #pragma unroll 1
         for (int q0 = 0, qb = 0; q0 < mK; q0 += 64, ++qb) {
