@@ -48,6 +48,16 @@ __device__ __forceinline__ double eval_linear(const XA& x, const YA& y, int n, i
     return lerp_np(xq, x(j), y(j), x(j + 1), y(j + 1));
 }
 
+// 1/b to <= 1 ulp: v_rcp_f64 + two Newton steps (the reciprocal the IEEE division expansion itself uses);
+// a third of the instructions of `1.0 / b`, no v_div_scale/fmas/fixup chain through VCC
+__device__ __forceinline__ double refined_rcp(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
 // One cubic-Hermite evaluation from knot slopes s (scipy PPoly coefficient build + Horner).
 template <class XA, class YA, class SA>
 __device__ __forceinline__ double eval_cubic(const XA& x, const YA& y, const SA& s, int n, int j, double xq,
@@ -57,7 +67,7 @@ __device__ __forceinline__ double eval_cubic(const XA& x, const YA& y, const SA&
     int jj = j > n - 2 ? n - 2 : j;
     double x0 = x(jj), y0 = y(jj), s0 = s(jj), s1 = s(jj + 1);
     double h = x(jj + 1) - x0;
-    double rh = 1.0 / h;
+    double rh = refined_rcp(h);
     double delta = (y(jj + 1) - y0) * rh;
     double t = (s0 + s1 - 2.0 * delta) * rh;
     double c0 = t * rh;
@@ -88,33 +98,31 @@ __device__ __forceinline__ void nak_slopes(const XA& x, const YA& y, SW& s, CW& 
     double xm = x(0), xc = x(1), xp = x(2);
     double ym = y(0), yc = y(1), yp = y(2);
     double dxm = xc - xm, dxc = xp - xc;             // dx[i-1], dx[i]
-    double dlm = (yc - ym) / dxm, dlc = (yp - yc) / dxc;
+    double dlm = (yc - ym) * refined_rcp(dxm), dlc = (yp - yc) * refined_rcp(dxc);
     double d = xp - xm;
-    double rhs = ((dxm + 2.0 * d) * dxc * dlm + dxm * dxm * dlc) / d;
-    double cprev = d / dxc;                          // up/di
-    double dprev = rhs / dxc;
+    double rhs = ((dxm + 2.0 * d) * dxc * dlm + dxm * dxm * dlc) * refined_rcp(d);
+    const double rdx1 = refined_rcp(dxc);
+    double cprev = d * rdx1;                         // up/di
+    double dprev = rhs * rdx1;
     cp.set(0, cprev); s.set(0, dprev);
     // interior rows i = 1..n-2: [dx_i, 2(dx_{i-1}+dx_i), dx_{i-1}]
     for (int i = 1; i <= n - 2; ++i) {
         rhs = 3.0 * (dxc * dlm + dxm * dlc);
-        double w = 2.0 * (dxm + dxc) - dxc * cprev;
-        cprev = dxm / w;
-        dprev = (rhs - dxc * dprev) / w;
+        const double rw = refined_rcp(2.0 * (dxm + dxc) - dxc * cprev);
+        cprev = dxm * rw;
+        dprev = (rhs - dxc * dprev) * rw;
         cp.set(i, cprev); s.set(i, dprev);
         if (i < n - 2) {
             xm = xc; xc = xp; xp = x(i + 2);
             ym = yc; yc = yp; yp = y(i + 2);
             dxm = dxc; dxc = xp - xc;
-            dlm = dlc; dlc = (yp - yc) / dxc;
+            dlm = dlc; dlc = (yp - yc) * refined_rcp(dxc);
         }
     }
     // last row (not-a-knot): [x_{n-1}-x_{n-3}, dx_{n-3}]; here dxm = dx[n-3], dxc = dx[n-2]
     d = xp - xm;
-    rhs = (dxc * dxc * dlm + (2.0 * d + dxc) * dxm * dlc) / d;
-    {
-        double w = dxm - d * cprev;
-        dprev = (rhs - d * dprev) / w;
-    }
+    rhs = (dxc * dxc * dlm + (2.0 * d + dxc) * dxm * dlc) * refined_rcp(d);
+    dprev = (rhs - d * dprev) * refined_rcp(dxm - d * cprev);
     double sn = dprev;
     s.set(n - 1, sn);
     for (int i = n - 2; i >= 0; --i) {

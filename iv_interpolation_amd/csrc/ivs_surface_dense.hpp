@@ -54,14 +54,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/b to <= 1 ulp: v_rcp_f64 + two Newton steps (the reciprocal the IEEE division expansion uses)
-__device__ __forceinline__ double refined_rcp(double b) {
-    double y = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-b, y, 1.0);
-    return __builtin_fma(y, e, y);
-}
 // exponent of |x| inside [2^-500, 2^500]: the range where the division expansion applies no scaling
 __device__ __forceinline__ bool div_safe(double x) {
     const double ax = __builtin_fabs(x);
