@@ -21,6 +21,9 @@ class _Runner:
     def threads(self):
         return int(self.lib.ivs_oracle_threads())
 
+    def set_threads(self, n):
+        self.lib.ivs_oracle_set_threads(int(n))
+
     def surface_batch(self, K, T, sigma, Kq, Tq, method, k_off=None):
         f = lambda a: np.ascontiguousarray(a, np.float64)   # noqa: E731
         K, T, sigma, Kq, Tq = f(K), f(T), f(sigma), f(Kq), f(Tq)
@@ -43,7 +46,21 @@ class _Runner:
         return out, st
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (GPU boxes give a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def load():
     if not os.path.exists(_PATH):
         raise FileNotFoundError(_PATH + " (run `make -C oracle`)")
-    return _Runner(C.CDLL(_PATH))
+    r = _Runner(C.CDLL(_PATH))
+    r.set_threads(usable_cpus())
+    return r

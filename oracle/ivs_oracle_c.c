@@ -98,6 +98,14 @@ static int interp1d(const double* xk, const double* yk, int ystride, int n, cons
     return 0;
 }
 
+void ivs_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int ivs_oracle_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
