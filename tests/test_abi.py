@@ -40,3 +40,22 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -22 and b"null pointer" in lib.ivs_last_error()
     rc = lib.ivs_interp1d_batch_f64(None, None, 0, None, 1, 1, 0, None, None, 0, None, 0, None, 7, None, 0, None)
     assert rc == -22
+
+
+def test_shape_validation_codes_without_gpu():
+    """Host-side validation returns errno-style codes before any launch (fake non-null pointers are never dereferenced)."""
+    import ctypes as C
+    lib = _lib.load()
+    P = C.c_void_p(64)
+    call = lambda **kw: lib.ivs_surface_batch_f64(  # noqa: E731
+        P, kw.get("k_off"), kw.get("k_stride", 64), kw.get("nK", 64), P, 0, kw.get("nT", 16), P, kw.get("B", 1),
+        P, 0, kw.get("mK", 64), P, 0, kw.get("mT", 16), P, None, kw.get("method", 0), 0, None)
+    assert call(B=0) == 0 and call(mK=0) == 0                      # empty batches / grids are a no-op
+    assert call(nT=33) == -34 and b"nT=33" in lib.ivs_last_error()  # IVS_ERANGE
+    assert call(nT=0) == -34
+    assert call(k_stride=10) == -22                                  # k_stride < nK
+    assert call(B=-1) == -22
+    assert call(nK=4000, k_stride=4000, method=1) == -34 and b"LDS" in lib.ivs_last_error()
+    assert lib.ivs_interp1d_batch_f64(P, P, 5, P, 1, 1, 10, None, P, 10, P, 10, P, 0, P, 1 << 20, None) == -22   # stride < rows
+    assert lib.ivs_interp1d_batch_f64(P, P, 10, P, 1, 1, 10, None, P, 10, P, 10, P, 0, P, 8, None) == -12        # workspace too small
+    assert lib.ivs_candle_aggregate_f64(P, P, P, P, P, P, P, 1, 10, 0, P, P, P, P, P, P, P, None) == -22          # freq 0

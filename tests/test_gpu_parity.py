@@ -328,3 +328,20 @@ def test_interpolate_frame_on_gpu_equals_per_symbol():
                 assert np.array_equal(got[c].to_numpy(), exp[c].to_numpy(), equal_nan=True), (method, c)
             else:
                 assert (got[c].astype(str) == exp[c].astype(str)).all(), (method, c)
+
+
+def test_wide_strike_grid_generic_and_empty_batch():
+    """nK = 200 (beyond the dense kernels) runs on the generic kernel; B = 0 is a no-op."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    d = synth.numpy_batch(40, 200, 16, seed=9)
+    Kq, Tq = synth.query_grids(64, 16)
+    for m in ("linear", "cubic", "pchip"):
+        got, st, kern = _run(d, Kq, Tq, m)
+        assert kern == "surface_generic_kernel"
+        ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[m])
+        assert np.array_equal(st, rst)
+        close(got, ref, m, f"nK=200 {m}")
+    out, st = engine.surface_batch(torch.empty((0, 64), dtype=torch.float64, device="cuda"), dev(d["T"]),
+                                   torch.empty((0, 16, 64), dtype=torch.float64, device="cuda"), dev(Kq), dev(Tq), "cubic")
+    assert out.shape == (0, 16, 64) and st.shape == (0,)
