@@ -16,6 +16,8 @@
 // Surfaces that contain a NaN quote (or batches whose Tq is not ascending) are tagged with a
 // sentinel in out[b][0] and redone by the generic kernel in a second, filtered launch.
 #pragma once
+#include <cstdlib>
+
 #include "ivs_surface_generic.hpp"
 
 namespace ivs {
@@ -506,28 +508,29 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         __syncthreads();                                   // everyone is done reading the previous surface's LDS
         stamp(-1);
         // ---- stage quotes: chunk i, lane -> row t = 2i + (lane>>5), k = 2*(lane&31)
-        bool bad = false;
+        unsigned long long bad = 0ull;                     // wave-level NaN mask, accumulated in scalar registers
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = 2 * i + (lane >> 5), k = 2 * (lane & 31);
             *reinterpret_cast<double2*>(&Y[t * D_RS + d_sl(k)]) = pre[i];
-            bad |= !(pre[i].x == pre[i].x) || !(pre[i].y == pre[i].y);
+            bad |= __ballot(pre[i].x != pre[i].x) | __ballot(pre[i].y != pre[i].y);
         }
         Ksh[lane] = pre_k;
         double* outb = p.out + b * (int64_t)mT * mK;
         if (!t_shared) t_phase(p.T + b * p.t_stride, p.Tq + b * p.tq_stride);   // contains a barrier
-        if (__ballot(bad) != 0ull || tt.unsorted) {        // wave-uniform: leave it to the generic kernel
+        if (bad != 0ull || tt.unsorted) {                  // wave-uniform: leave it to the generic kernel
             if (lane == 0) reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;
-            if (b + gridDim.x < p.B) prefetch(b + gridDim.x);
+            prefetch(b + gridDim.x < p.B ? b + gridDim.x : p.B - 1);
             continue;
         }
         __syncthreads();
         stamp(0);
         const double* Kqb = p.Kq + b * p.kq_stride;
         if (!kq_shared) load_xq(Kqb);
-        {
+        {   // next surface's loads fly during the whole computation; past the end the last surface is re-read
+            // (harmless) so that the prefetch registers are written on every path
             const int64_t bn = b + gridDim.x;
-            if (bn < p.B) prefetch(bn);                    // next surface's loads fly during the whole computation
+            prefetch(bn < p.B ? bn : p.B - 1);
         }
         if (CUB) {
             dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
                 }
             }
             stamp(3);
-            dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, act, mT, mK, stamp);
+            if (act) dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, true, mT, mK, stamp);
             stamp(5);
         }
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
@@ -649,7 +652,8 @@ inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t 
     if (p.k_stride != 0 && p.k_stride < DK) return 0;
     if (reinterpret_cast<uintptr_t>(p.sigma) & 15) return 0;
     if (p.mT > D_MAX_MT) return 0;
-    const size_t lds = dense_lds_bytes(p.mT);
+    size_t lds = dense_lds_bytes(p.mT);
+    if (const char* pad = getenv("IVS_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy-sensitivity experiments only
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu > 8 ? 8 : per_cu;
