@@ -284,21 +284,21 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
 
     while (b < p.B) {
         __syncthreads();
-        bool bad = false;
+        unsigned long long bad = 0ull;                     // wave-level NaN mask in scalar registers
 #pragma unroll
         for (int t = 0; t < DT; ++t)
 #pragma unroll
             for (int blk = 0; blk < NKB; ++blk) {
                 const double v = pre[t * NKB + blk];
                 Y[t * RS + d_sl(blk * 64 + lane)] = v;
-                bad |= !(v == v);
+                bad |= __ballot(v != v);
             }
 #pragma unroll
         for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
         double* outb = p.out + b * (int64_t)mT * mK;
         const double* Kqb = p.Kq + b * p.kq_stride;
         const int64_t b_next = seek(b + gridDim.x, n_next, koff_next);
-        const bool redo = __ballot(bad) != 0ull || tt.unsorted;
+        const bool redo = bad != 0ull || tt.unsorted;
         if (redo) {
             tag(b);
         } else {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
                         }
                     }
                 }
-                dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, act, mT, mK, nostamp);
+                if (act) dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp);
             }
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         }
