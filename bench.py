@@ -186,6 +186,20 @@ def main():
         check = {"surfaces": a.check, "max_abs_diff_vs_oracle": float(np.nanmax(np.abs(got - ref))),
                  "bit_exact": bool(np.array_equal(got, ref, equal_nan=True))}
 
+    copy_gbps = None
+    if rank == 0 and world == 1:
+        # context: what a plain device copy reaches on THIS device (read + write stream), same HIP-event timing
+        nbytes = 2 << 30
+        src = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda").fill_(1.0); dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record(); torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * nbytes / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         total = B * world
         bytes_launch = algorithmic_bytes(B, nK, nT, mK, mT, total_strikes)
@@ -201,6 +215,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(a.workload, a.method, kernel),
                          "kernel": kernel, "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms),
+                         "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2],
+                         "device_copy_GBps": copy_gbps, "frac_of_device_copy": (achieved / copy_gbps) if copy_gbps else None,
                          "algorithmic_bytes_per_launch": bytes_launch, "timing": "HIP events around each launch on the launch stream"},
             "parity_check": check,
         }
