@@ -58,6 +58,25 @@ __device__ __forceinline__ double refined_rcp(double b) {
     return __builtin_fma(y, e, y);
 }
 
+// The same with the interval slopes dy/dx precomputed (np.interp does this too when there are fewer knots than
+// queries: identical values, identical rounding).
+template <class XA, class YA, class SA>
+__device__ __forceinline__ double eval_linear_slopes(const XA& x, const YA& y, const SA& slope, int n, int j, double xq,
+                                                     bool right_hold) {
+#pragma clang fp contract(off)
+    if (j < 0) return qnan();
+    if (j >= n - 1) return (right_hold || xq == x(n - 1)) ? y(n - 1) : qnan();
+    const double x0 = x(j), y0 = y(j);
+    if (x0 == xq) return y0;
+    const double sl = slope(j);
+    double r = sl * (xq - x0) + y0;
+    if (__builtin_isnan(r)) {
+        r = sl * (xq - x(j + 1)) + y(j + 1);
+        if (__builtin_isnan(r) && y0 == y(j + 1)) r = y0;
+    }
+    return r;
+}
+
 // One cubic-Hermite evaluation from knot slopes s (scipy PPoly coefficient build + Horner).
 template <class XA, class YA, class SA>
 __device__ __forceinline__ double eval_cubic(const XA& x, const YA& y, const SA& s, int n, int j, double xq,

@@ -23,8 +23,11 @@ __host__ __device__ inline size_t interp1d_ws_bytes(int64_t total_knots, int64_t
     return (size_t)4 * C * (size_t)total_knots * 8 + (size_t)S * C * 4 + 64;
 }
 
+constexpr int P1_STAGE = 512;    // knots per (series, channel) whose slope solve runs out of LDS
+
 __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p) {
     __shared__ int wave_cnt[4];
+    __shared__ double px[P1_STAGE], py[P1_STAGE], ps[P1_STAGE], pc[P1_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sc = blockIdx.x;
     const int64_t s = sc / p.C; const int c = (int)(sc % p.C);
@@ -52,14 +55,27 @@ __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p)
         __syncthreads();
     }
     const int minkn = method_min_knots(p.method);
+    const bool solve = method_is_cubic(p.method) && base >= minkn && base >= 2;      // block-uniform
+    double* gs = p.ws + (int64_t)c * p.total_knots + a;
     if (tid == 0) {
         p.wn[sc] = (int32_t)base;
         p.status[sc] = (base > 0 && base < minkn) ? IVS_ST_TOO_FEW_KNOTS : IVS_ST_OK;
-        if (method_is_cubic(p.method) && base >= minkn && base >= 2) {
-            CView xv{wx, 1}, yv{wy, 1};
-            View sv{p.ws + (int64_t)c * p.total_knots + a, 1}, cv{p.wcp + (int64_t)c * p.total_knots + a, 1};
+    }
+    if (solve && base <= P1_STAGE) {
+        // the serial recurrence reads its knots from LDS (one global round trip per step would dominate)
+        for (int i = tid; i < (int)base; i += 256) { px[i] = wx[i]; py[i] = wy[i]; }
+        __syncthreads();
+        if (tid == 0) {
+            CView xv{px, 1}, yv{py, 1};
+            View sv{ps, 1}, cv{pc, 1};
             method_slopes(p.method, xv, yv, sv, cv, (int)base);
         }
+        __syncthreads();
+        for (int i = tid; i < (int)base; i += 256) gs[i] = ps[i];
+    } else if (solve && tid == 0) {
+        CView xv{wx, 1}, yv{wy, 1};
+        View sv{gs, 1}, cv{p.wcp + (int64_t)c * p.total_knots + a, 1};
+        method_slopes(p.method, xv, yv, sv, cv, (int)base);
     }
 }
 
@@ -72,24 +88,59 @@ __device__ __forceinline__ int64_t series_of(const int64_t* off, int64_t S, int6
     return lo;
 }
 
+// Blocks of 256 consecutive output rows almost always lie inside ONE series (a symbol has thousands of minute rows):
+// two lanes find the series of the block's first and last row, and when they agree the series' compacted knots
+// (x, y, slopes) are staged in LDS once per channel, so the per-row binary search and the evaluation read LDS instead
+// of chasing 6-12 dependent global loads per row.  Blocks that straddle series, or series with more than
+// E1_STAGE knots, use the global arrays directly.
+constexpr int E1_STAGE = 512;
+
 __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= p.total_q) return;
-    const int64_t s = series_of(p.q_off, p.S, g);
+    __shared__ double sx[E1_STAGE], sy[E1_STAGE], ss[E1_STAGE];
+    __shared__ int64_t s_edge[2];
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * 256;
+    const int64_t g = g0 + tid;
+    const bool active = g < p.total_q;
+    const int64_t g_last = g0 + 255 < p.total_q ? g0 + 255 : p.total_q - 1;
+    if (tid == 0) s_edge[0] = series_of(p.q_off, p.S, g0);
+    if (tid == 64) s_edge[1] = series_of(p.q_off, p.S, g_last);
+    __syncthreads();
+    const int64_t s_first = s_edge[0], s_last = s_edge[1];
+    const bool one_series = s_first == s_last;                 // block-uniform
+    int64_t s = s_first;
+    if (!one_series && active) {                               // few candidates: walk
+        while (s < s_last && p.q_off[s + 1] <= g) ++s;
+    }
     const int64_t a = p.knot_off[s];
-    const double xq = p.xq ? p.xq[g] : (double)(g - p.q_off[s]);
+    const double xq = !active ? qnan() : (p.xq ? p.xq[g] : (double)(g - p.q_off[s]));
     const int method = p.method;
+    const bool cubic = method_is_cubic(method);
+    const bool lerp_method = method == IVS_LINEAR || method == IVS_SLINEAR;
     const int minkn = method_min_knots(method);
     for (int c = 0; c < p.C; ++c) {
-        int n = p.wn[s * p.C + c];
-        double r = qnan();
-        if (n > 0 && n >= minkn) {
-            CView x{p.wx + (int64_t)c * p.total_knots + a, 1}, y{p.wy + (int64_t)c * p.total_knots + a, 1};
-            int j = find_interval(x, n, xq);
-            CView sl{p.ws + (int64_t)c * p.total_knots + a, 1};
-            r = eval_method(method, x, y, sl, n, j, xq);
+        const int n = p.wn[s * p.C + c];
+        const double* gx = p.wx + (int64_t)c * p.total_knots + a;
+        const double* gy = p.wy + (int64_t)c * p.total_knots + a;
+        const double* gs = p.ws + (int64_t)c * p.total_knots + a;
+        const bool staged = one_series && n > 0 && n <= E1_STAGE;      // block-uniform
+        if (staged) {
+            __syncthreads();                                   // previous channel's readers are done
+            for (int i = tid; i < n; i += 256) { sx[i] = gx[i]; sy[i] = gy[i]; if (cubic) ss[i] = gs[i]; }
+            __syncthreads();
+            if (lerp_method) {     // np.interp's per-interval slope (dy/dx, IEEE division) once per knot instead of per row
+                for (int i = tid; i + 1 < n; i += 256) ss[i] = (sy[i + 1] - sy[i]) / (sx[i + 1] - sx[i]);
+                __syncthreads();
+            }
         }
-        p.out[c * p.out_stride + g] = r;
+        double r = qnan();
+        if (active && n > 0 && n >= minkn) {
+            CView x{staged ? sx : gx, 1}, y{staged ? sy : gy, 1}, sl{staged ? ss : gs, 1};
+            const int j = find_interval(x, n, xq);
+            if (staged && lerp_method) r = eval_linear_slopes(x, y, sl, n, j, xq, method == IVS_LINEAR);
+            else r = eval_method(method, x, y, sl, n, j, xq);
+        }
+        if (active) p.out[c * p.out_stride + g] = r;
     }
 }
 
@@ -98,23 +149,52 @@ struct FfillParams {
     const int64_t* q_off; int64_t S; int64_t total_q; int32_t* idx_out; int64_t out_stride;
 };
 
+// Same block structure as the eval kernel: the positions (and validity bytes) of the series' source rows are staged
+// in LDS when the block lies inside one series with at most F1_STAGE source rows.
+constexpr int F1_STAGE = 512;
+constexpr int F1_COLS = 12;
+
 __global__ __launch_bounds__(256) void ffill_index_kernel(FfillParams p) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= p.total_q) return;
-    const int64_t s = series_of(p.q_off, p.S, g);
-    const int64_t pos = g - p.q_off[s];
+    __shared__ int64_t spos[F1_STAGE];
+    __shared__ uint8_t sval[F1_COLS][F1_STAGE];
+    __shared__ int64_t s_edge[2];
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * 256;
+    const int64_t g = g0 + tid;
+    const bool active = g < p.total_q;
+    const int64_t g_last = g0 + 255 < p.total_q ? g0 + 255 : p.total_q - 1;
+    if (tid == 0) s_edge[0] = series_of(p.q_off, p.S, g0);
+    if (tid == 64) s_edge[1] = series_of(p.q_off, p.S, g_last);
+    __syncthreads();
+    const int64_t s_first = s_edge[0], s_last = s_edge[1];
+    int64_t s = s_first;
+    if (s_first != s_last && active) {
+        while (s < s_last && p.q_off[s + 1] <= g) ++s;
+    }
     const int64_t lo0 = p.src_off[s], hi0 = p.src_off[s + 1];
-    int64_t lo = lo0, hi = hi0;       // first j with src_pos[j] > pos
+    const int64_t nsrc = hi0 - lo0;
+    const bool staged = s_first == s_last && nsrc <= F1_STAGE && p.n_cols <= F1_COLS;      // block-uniform
+    if (staged) {
+        for (int i = tid; i < nsrc; i += 256) {
+            spos[i] = p.src_pos[lo0 + i];
+            for (int c = 0; c < p.n_cols; ++c) sval[c][i] = p.valid[c * p.valid_stride + lo0 + i];
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const int64_t pos = g - p.q_off[s];
+    int64_t lo = 0, hi = nsrc;                                 // first local j with src_pos[j] > pos
     while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (p.src_pos[mid] <= pos) lo = mid + 1; else hi = mid;
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t v = staged ? spos[mid] : p.src_pos[lo0 + mid];
+        if (v <= pos) lo = mid + 1; else hi = mid;
     }
     const int64_t jlast = lo - 1;
     for (int c = 0; c < p.n_cols; ++c) {
-        const uint8_t* v = p.valid + c * p.valid_stride;
         int64_t j = jlast;
-        while (j >= lo0 && !v[j]) --j;
-        p.idx_out[c * p.out_stride + g] = j >= lo0 ? (int32_t)j : -1;
+        if (staged) { while (j >= 0 && !sval[c][j]) --j; }
+        else { const uint8_t* v = p.valid + c * p.valid_stride + lo0; while (j >= 0 && !v[j]) --j; }
+        p.idx_out[c * p.out_stride + g] = j >= 0 ? (int32_t)(lo0 + j) : -1;
     }
 }
 
