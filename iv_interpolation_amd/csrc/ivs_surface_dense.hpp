@@ -16,8 +16,6 @@
 // Surfaces that contain a NaN quote (or batches whose Tq is not ascending) are tagged with a
 // sentinel in out[b][0] and redone by the generic kernel in a second, filtered launch.
 #pragma once
-#include <cstdlib>
-
 #include "ivs_surface_generic.hpp"
 
 namespace ivs {
@@ -652,8 +650,7 @@ inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t 
     if (p.k_stride != 0 && p.k_stride < DK) return 0;
     if (reinterpret_cast<uintptr_t>(p.sigma) & 15) return 0;
     if (p.mT > D_MAX_MT) return 0;
-    size_t lds = dense_lds_bytes(p.mT);
-    if (const char* pad = getenv("IVS_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy-sensitivity experiments only
+    const size_t lds = dense_lds_bytes(p.mT);
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu > 8 ? 8 : per_cu;
