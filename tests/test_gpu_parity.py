@@ -345,3 +345,30 @@ def test_wide_strike_grid_generic_and_empty_batch():
     out, st = engine.surface_batch(torch.empty((0, 64), dtype=torch.float64, device="cuda"), dev(d["T"]),
                                    torch.empty((0, 16, 64), dtype=torch.float64, device="cuda"), dev(Kq), dev(Tq), "cubic")
     assert out.shape == (0, 16, 64) and st.shape == (0,)
+
+
+def test_buffer_reuse_misaligned_views_and_wide_grids():
+    """(1) the same output buffer reused across launches with and without NaN surfaces (redo sentinel never goes
+    stale); (2) an 8-byte-offset (not 16-byte aligned) sigma view takes the variable-shape kernel; (3) mK = 1000."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    Kq, Tq = synth.query_grids(64, 16)
+    clean = synth.numpy_batch(500, 64, 16, seed=1)
+    dirty = synth.numpy_batch(500, 64, 16, seed=2, nan_frac=0.05)
+    out = torch.empty((500, 16, 64), dtype=torch.float64, device="cuda"); st = torch.empty(500, dtype=torch.int32, device="cuda")
+    for d in (clean, dirty, clean, dirty):
+        engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), "cubic", out=out, status=st)
+        ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, O.CUBIC)
+        assert np.array_equal(st.cpu().numpy(), rst)
+        close(out.cpu().numpy(), ref, "cubic", "buffer reuse")
+    flat = torch.empty(500 * 1024 + 1, dtype=torch.float64, device="cuda")
+    view = flat[1:].view(500, 16, 64); view.copy_(dev(clean["sigma"]))
+    assert view.data_ptr() % 16 == 8
+    got, _ = engine.surface_batch(dev(clean["K"]), dev(clean["T"]), view, dev(Kq), dev(Tq), "linear")
+    assert "dense_var" in engine.last_kernel()
+    ref, _ = O.surface_batch(clean["K"], clean["T"], clean["sigma"], Kq, Tq, O.LINEAR)
+    close(got.cpu().numpy(), ref, "linear", "misaligned view")
+    Kq2, Tq2 = synth.query_grids(1000, 64)
+    got, _ = engine.surface_batch(dev(clean["K"][:50]), dev(clean["T"]), dev(clean["sigma"][:50]), dev(Kq2), dev(Tq2), "cubic")
+    ref, _ = O.surface_batch(clean["K"][:50], clean["T"], clean["sigma"][:50], Kq2, Tq2, O.CUBIC)
+    close(got.cpu().numpy(), ref, "cubic", "mK=1000")
