@@ -95,19 +95,29 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
         __syncthreads();   // previous surface's readers are done with LDS
         for (int k = lane; k < nKb; k += 64) Ksh[k] = Kb[k];
         if (lane < nT) Tsh[lane] = Tb[lane];
-        // 1. load + compact rows
-        for (int t = 0; t < nT; ++t) {
-            int cnt = 0;
-            for (int c0 = 0; c0 < nKb; c0 += 64) {
-                int k = c0 + lane;
-                double v = k < nKb ? sb[(int64_t)t * nKb + k] : qnan();
-                bool valid = !__builtin_isnan(v);
-                unsigned long long m = __ballot(valid);
-                int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                if (valid) { xs[t * LK + rank] = Kb[k]; ys[t * LK + rank] = v; }
-                cnt += __popcll(m);
+        // 1. load + compact rows.  All rows of a 64-strike chunk are loaded back to back (one memory round trip per
+        //    chunk instead of one per row), then compacted row by row with a wave ballot.
+        if (lane < nT) nrow[lane] = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < nKb; c0 += 64) {
+            const int k = c0 + lane;
+            const bool in = k < nKb;
+            double v[GEN_NTMAX];
+#pragma unroll
+            for (int t = 0; t < GEN_NTMAX; ++t) v[t] = (t < nT && in) ? sb[(int64_t)t * nKb + k] : qnan();
+            const double kx = in ? Kb[k] : 0.0;
+#pragma unroll
+            for (int t = 0; t < GEN_NTMAX; ++t) {
+                if (t < nT) {                                  // wave-uniform
+                    const bool valid = !__builtin_isnan(v[t]);
+                    const unsigned long long m = __ballot(valid);
+                    const int cnt = nrow[t];
+                    const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    if (valid) { xs[t * LK + rank] = kx; ys[t * LK + rank] = v[t]; }
+                    if (lane == 0) nrow[t] = cnt + __popcll(m);
+                }
             }
-            if (lane == 0) nrow[t] = cnt;
+            __syncthreads();
         }
         __syncthreads();
         // 2. strike-direction slopes, lane = row
