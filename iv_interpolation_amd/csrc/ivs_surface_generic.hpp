@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
             CView kfull{Ksh, 1};
             int jfull = find_interval(kfull, nKb, xq);
             int cn = 0;   // valid knots in this lane's column
+#pragma unroll 4
             for (int t = 0; t < nT; ++t) {
                 int n = nrow[t];
                 double z = qnan();
@@ -162,13 +163,20 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
             if (few && active) st |= IVS_ST_TOO_FEW_KNOTS;
             bool solvable = cn > 0 && !few;
             if (cubic && solvable && cn >= 2) method_slopes(method, cx, cy, csv, ccp, cn);
+            // query maturities are normally ascending: march the interval pointer instead of a binary search per row
+            // (each search step costs two dependent LDS reads through the index column)
+            int jc = -1;
+            double xprev = -__builtin_inf();
+#pragma unroll 4
             for (int tq = 0; tq < p.mT; ++tq) {
                 double r = qnan();
                 if (solvable) {
-                    double x = Tqb[tq];
-                    int j = find_interval(cx, cn, x);
+                    const double x = Tqb[tq];
+                    if (x >= xprev) { while (jc + 1 < cn && cx(jc + 1) <= x) ++jc; }
+                    else jc = find_interval(cx, cn, x);
+                    xprev = x;
                     CView csr{cs + lane, 64};
-                    r = eval_method(method, cx, cy, csr, cn, j, x);
+                    r = eval_method(method, cx, cy, csr, cn, jc, x);
                 }
                 if (active) outb[(int64_t)tq * p.mK + q] = r;
             }
