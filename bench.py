@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--method", default="cubic", choices=["linear", "cubic", "cubicspline", "slinear"])
+    ap.add_argument("--method", default="cubic", choices=["linear", "cubic", "cubicspline", "slinear", "pchip", "akima"])
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1_000_000, help="surfaces per GPU (weak scaling)")
     ap.add_argument("--nk", type=int, default=0, help="override the strike count of a uniform workload (variable-shape kernel)")

@@ -34,6 +34,12 @@ __host__ __device__ inline size_t dense_lds_bytes(int mT) {
     return (size_t)(2 * DT * D_RS + 64 + 64 + 64 + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
 }
 
+// method families of the dense kernels
+__host__ __device__ constexpr bool d_is_nak(int m) { return m == IVS_CUBIC || m == IVS_CUBICSPLINE; }      // tridiagonal slopes
+__host__ __device__ constexpr bool d_is_local(int m) { return m == IVS_PCHIP || m == IVS_AKIMA; }          // 3-/5-point slopes
+__host__ __device__ constexpr bool d_is_hermite(int m) { return d_is_nak(m) || d_is_local(m); }
+__host__ __device__ constexpr bool d_extrap_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }
+
 // codes of a query row in the maturity direction
 constexpr int TQ_LEFT = -1, TQ_HOLD = 15, TQ_NAN = 16;
 
@@ -195,6 +201,181 @@ __device__ __forceinline__ double seg16_suffix_prod(double v, int lane) {
     return v;
 }
 
+// ---- local-slope methods (pchip, akima): a knot's slope depends on the 2 (pchip) or 4 (akima) neighbouring
+// secants only, so there is no system to solve: uniform per-knot tables + per-lane arithmetic.
+// Tables on N knots X[0..N), entry i:  r0 = 1/dx_i (0 for i = N-1);  pchip: (r1, r2) = (w1, w2) =
+// (2 dx_i + dx_{i-1}, dx_i + 2 dx_{i-1}) for interior knots, and for the two end knots the coefficients of the
+// one-sided three-point formula d = r1*m_near - r2*m_far (scipy _cubic.py _edge_case: ((2h0+h1) m0 - h0 m1)/(h0+h1)).
+template <int N>
+__device__ __forceinline__ void local_tables(const double* X, int i, double& r0, double& r1, double& r2) {
+    const double x0 = X[i];
+    const double xp = X[i + 1 < N ? i + 1 : N - 1], xm = X[i > 0 ? i - 1 : 0];
+    const double dxc = xp - x0, dxm = x0 - xm;
+    r0 = i < N - 1 ? refined_rcp(dxc) : 0.0;
+    const bool first = i == 0, last = i == N - 1;
+    const double h0 = first ? dxc : dxm;
+    const double h1 = first ? X[2] - X[1] : X[N - 2] - X[N - 3];
+    const double rs = refined_rcp(h0 + h1);
+    r1 = (first || last) ? (2.0 * h0 + h1) * rs : 2.0 * dxc + dxm;
+    r2 = (first || last) ? h0 * rs : dxc + 2.0 * dxm;
+}
+// interior knot: weighted harmonic mean of the two secants, 1/((w1/mp + w2/mk)/(w1+w2)) in one division
+__device__ __forceinline__ double pchip_knot(double mp, double mk, double w1, double w2) {
+    const double d = (w1 + w2) * mp * mk * refined_rcp(w1 * mk + w2 * mp);
+    return (mp * mk > 0.0) ? d : 0.0;
+}
+__device__ __forceinline__ double pchip_edge(double m0, double m1, double ea, double eb) {
+    const double d = ea * m0 - eb * m1;
+    const bool clip = !(m0 * m1 > 0.0) && __builtin_fabs(d) > 3.0 * __builtin_fabs(m0);
+    const double r = clip ? 3.0 * m0 : d;
+    return (d * m0 > 0.0) ? r : 0.0;                       // branch-free on purpose (selects)
+}
+// akima (scipy _cubic.py:510-541): secants ma..md = m_{i-2}, m_{i-1}, m_i, m_{i+1}
+__device__ __forceinline__ double akima_f12(double ma, double mb, double mc, double md) {
+    return __builtin_fabs(md - mc) + __builtin_fabs(mb - ma);
+}
+__device__ __forceinline__ double akima_knot(double ma, double mb, double mc, double md, double thr) {
+    const double f1 = __builtin_fabs(md - mc), f2 = __builtin_fabs(mb - ma), f12 = f1 + f2;
+    const double t = (f1 * mb + f2 * mc) * refined_rcp(f12);
+    return f12 > thr ? t : 0.5 * (md + ma);
+}
+constexpr int DPP_QUAD_SWAP1 = 0xB1, DPP_QUAD_SWAP2 = 0x4E;    // quad_perm [1,0,3,2] / [2,3,0,1]
+
+// Strike-direction slopes for the local methods, rs-lane layout as in dense_strike_slopes: reads Y and Ksh,
+// writes RDX and (last) the S plane; the three tables alias the S plane until then.  All 64 lanes must call it.
+template <int METHOD>
+__device__ __forceinline__ void dense_strike_slopes_local(const double* Y, double* S, const double* Ksh, double* RDX,
+                                                          int lane) {
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    double* R0 = S;
+    double* R1 = S + 80;                // one spare slot behind each table: R0[kp + 18] of segment 3 stays inside
+    double* R2 = S + 160;
+    {
+        double r0, r1, r2;
+        local_tables<DK>(Ksh, lane, r0, r1, r2);
+        const int kl = d_sl(lane);
+        R0[kl] = r0; R1[kl] = r1; R2[kl] = r2; RDX[lane] = r0;
+    }
+    __syncthreads();
+    const int rs_t = lane >> 2, rs_seg = lane & 3;
+    const double* yr = Y + rs_t * D_RS;
+    const int kp = rs_seg * 18;
+    const bool s_first = rs_seg == 0, s_last = rs_seg == 3;
+    double y[20];                                   // y[m+2] = y_{kb+m}, m = -2..17
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(yr + kp + 2 * c);
+        y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
+    }
+    y[1] = yr[s_first ? 0 : kp - 3];
+    y[18] = yr[s_last ? 0 : kp + 18];
+    if (AK) { y[0] = yr[s_first ? 0 : kp - 4]; y[19] = yr[s_last ? 0 : kp + 19]; }
+    // secants m_{kb-2+i}, i = 0..18: intervals kb-2 .. kb+16 (pchip needs i = 1..17 only)
+    auto sec = [&](int i) {
+        const int ti = i == 0 ? kp - 4 : (i == 1 ? kp - 3 : (i == 18 ? kp + 18 : kp + i - 2));
+        return (y[i + 1] - y[i]) * R0[(s_first && i < 2) ? 0 : ti];
+    };
+    double d[16];
+    if (!AK) {
+        double mp = sec(1), mk = sec(2);            // rolling pair (m_{k-1}, m_k): keeps the live set small
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const double mn = m < 15 ? sec(m + 3) : 0.0;           // m_{k+1}
+            const double w1 = R1[kp + m], w2 = R2[kp + m];
+            double v = pchip_knot(mp, mk, w1, w2);
+            if (m == 0) { const double e = pchip_edge(mk, mn, w1, w2); v = s_first ? e : v; }
+            if (m == 15) { const double e = pchip_edge(mp, sec(15), w1, w2); v = s_last ? e : v; }
+            d[m] = v;
+            mp = mk; mk = mn;
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound the live range of the division chains
+        }
+    } else {
+        // secants beyond the ends by linear extrapolation of the secant sequence; two rolling passes (the row's
+        // largest |second difference| first, then the slopes) instead of a 19-entry secant array
+        const double l1 = 2.0 * sec(2) - sec(3), l0 = 2.0 * l1 - sec(2);
+        const double r17 = 2.0 * sec(16) - sec(15), r18 = 2.0 * r17 - sec(16);
+        auto secx = [&](int i) {
+            double v = sec(i);
+            if (i == 0) v = s_first ? l0 : v;
+            if (i == 1) v = s_first ? l1 : v;
+            if (i == 17) v = s_last ? r17 : v;
+            if (i == 18) v = s_last ? r18 : v;
+            return v;
+        };
+        double fmax = 0.0;
+        {
+            double ma = secx(0), mb = secx(1), mc = secx(2);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const double md = secx(m + 3);
+                fmax = __builtin_fmax(fmax, akima_f12(ma, mb, mc, md));
+                ma = mb; mb = mc; mc = md;
+            }
+        }
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));      // the row's 4 segments = one quad
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
+        const double thr = 1e-9 * fmax;
+        double ma = secx(0), mb = secx(1), mc = secx(2);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const double md = secx(m + 3);
+            d[m] = akima_knot(ma, mb, mc, md, thr);
+            ma = mb; mb = mc; mc = md;
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                               // all table reads done: the S plane may be overwritten
+    double* srow = S + rs_t * D_RS + kp;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
+        *reinterpret_cast<double2*>(srow + 2 * c) = v;
+    }
+}
+
+// The same slopes in the maturity direction: 16 knots per lane in registers, tables TT[i] = {r0, r1, r2, -}.
+template <int METHOD>
+__device__ __forceinline__ void dense_maturity_slopes_local(const double (&z)[DT], const double* TT, double (&s)[DT]) {
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    auto sec = [&](int i) { return (z[i + 1] - z[i]) * TT[i * 4]; };       // m_i, i = 0..14
+    if (!AK) {
+        double mp = sec(0), mk = sec(1);
+        s[0] = pchip_edge(mp, mk, TT[1], TT[2]);
+#pragma unroll
+        for (int i = 1; i < DT - 1; ++i) {          // (mp, mk) = (m_{i-1}, m_i)
+            s[i] = pchip_knot(mp, mk, TT[i * 4 + 1], TT[i * 4 + 2]);
+            if (i < DT - 2) { mp = mk; mk = sec(i + 1); }
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        s[DT - 1] = pchip_edge(mk, mp, TT[(DT - 1) * 4 + 1], TT[(DT - 1) * 4 + 2]);
+    } else {
+        const double l1 = 2.0 * sec(0) - sec(1), l0 = 2.0 * l1 - sec(0);                       // m_{-1}, m_{-2}
+        const double r15 = 2.0 * sec(DT - 2) - sec(DT - 3), r16 = 2.0 * r15 - sec(DT - 2);     // m_15, m_16
+        auto secx = [&](int i) {                    // m_i, i = -2..16
+            return i == -2 ? l0 : (i == -1 ? l1 : (i == DT - 1 ? r15 : (i == DT ? r16 : sec(i < 0 ? 0 : (i > DT - 2 ? DT - 2 : i)))));
+        };
+        double fmax = 0.0;
+        {
+            double ma = secx(-2), mb = secx(-1), mc = secx(0);
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const double md = secx(i + 1);
+                fmax = __builtin_fmax(fmax, akima_f12(ma, mb, mc, md));
+                ma = mb; mb = mc; mc = md;
+            }
+        }
+        const double thr = 1e-9 * fmax;
+        double ma = secx(-2), mb = secx(-1), mc = secx(0);
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            const double md = secx(i + 1);
+            s[i] = akima_knot(ma, mb, mc, md, thr);
+            ma = mb; mb = mc; mc = md;
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Strike-direction slopes of all 16 rows of the staged surface: K-phase (k-lane factorisation) followed by
 // the segmented sweeps (rs-lane).  Reads Y and Ksh, writes RDX and (last) the S plane; the factor tables
 // live in the S plane until then.  Must be called by all 64 lanes of the workgroup.
@@ -295,14 +476,19 @@ struct TqTables {
 template <int METHOD, bool WLDS>
 __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tqb, int mT, int lane, double* Tsh,
                                               double* TT, double* W, TqTables& tt) {
-    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool CUB = d_is_hermite(METHOD);
     constexpr bool w_lds = WLDS;
     if (lane < DT) Tsh[lane] = Tb[lane];
     __syncthreads();
-    if (CUB) {
+    if (d_is_nak(METHOD)) {
         double al, cp, pp, qq, rdx;
         factor_tables<DT>(Tsh, lane, al, cp, pp, qq, rdx);
         if (lane < DT) { TT[lane * 4 + 0] = pp; TT[lane * 4 + 1] = qq; TT[lane * 4 + 2] = al; TT[lane * 4 + 3] = cp; }
+    }
+    if (d_is_local(METHOD) && lane < DT) {
+        double r0, r1, r2;
+        local_tables<DT>(Tsh, lane, r0, r1, r2);
+        TT[lane * 4 + 0] = r0; TT[lane * 4 + 1] = r1; TT[lane * 4 + 2] = r2; TT[lane * 4 + 3] = 0.0;
     }
     const int tq = lane;
     const bool act = tq < mT;
@@ -319,7 +505,7 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
     else if (j >= DT - 1) {
         if (METHOD == IVS_LINEAR) code = TQ_HOLD;
         else if (METHOD == IVS_SLINEAR) code = (x == tl) ? TQ_HOLD : TQ_NAN;
-        else if (METHOD == IVS_CUBIC) code = (x == tl) ? DT - 2 : TQ_NAN;
+        else if (!d_extrap_right(METHOD)) code = (x == tl) ? DT - 2 : TQ_NAN;
         else code = DT - 2;
     } else code = j;
     const int jj = code >= 0 && code <= DT - 2 ? code : 0;
@@ -360,7 +546,7 @@ template <int METHOD, bool WLDS, class StampFn>
 __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const TqTables& tt, const double* TT,
                                                     const double* W, double* outb, int q0, int lane, bool act, int mT,
                                                     int mK, StampFn&& stamp) {
-    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool CUB = d_is_hermite(METHOD);
     constexpr bool w_lds = WLDS;
     const double nanv = __builtin_nan("");
     // ---- maturity direction (q-lane, registers).  Row pointers are wave-uniform (scalar base),
@@ -388,7 +574,13 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
     if (CUB) {
         double s[DT];
         double prev = 0.0;
-        {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
+        if (d_is_local(METHOD)) {
+            dense_maturity_slopes_local<METHOD>(z, TT, s);
+            // pin the slopes here: otherwise they (and, transitively, the strike evaluation with its 64 gathered
+            // operands) are sunk into the row loops below and the live set overflows the register file
+#pragma unroll
+            for (int i = 0; i < DT; ++i) asm volatile("" : "+v"(s[i]));
+        } else {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
             constexpr int LA = 4;
             double2 tpq[4], tac[4];
 #pragma unroll
@@ -447,7 +639,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
 
 template <int METHOD, bool TSHARED, bool WLDS, bool STAMP = false>
 __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, unsigned long long* dbg = nullptr) {
-    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool CUB = d_is_hermite(METHOD);
     unsigned long long acc[D_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
     auto stamp = [&](int i) {
@@ -530,8 +722,12 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
             const int64_t bn = b + gridDim.x;
             prefetch(bn < p.B ? bn : p.B - 1);
         }
-        if (CUB) {
+        if (d_is_nak(METHOD)) {
             dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
+            __syncthreads();
+            stamp(2);
+        } else if (d_is_local(METHOD)) {
+            dense_strike_slopes_local<METHOD>(Y, S, Ksh, RDX, lane);
             __syncthreads();
             stamp(2);
         }
@@ -556,7 +752,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
             const int o0 = d_sl(jj), o1 = d_sl(jj + 1);
             double z[DT];
             if (CUB) {
-                const bool ok = !left && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
+                const bool ok = !left && ((xq <= xl) || d_extrap_right(METHOD));
                 const double u = xq - x0, t = u * RDX[jj], omt = 1.0 - t;
                 const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
                 const double w1 = t * t * (3.0 - 2.0 * t);
@@ -609,6 +805,10 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
                 }
             }
             stamp(3);
+            if (d_is_local(METHOD)) {
+#pragma unroll
+                for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
+            }
             if (act) dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, true, mT, mK, stamp);
             stamp(5);
         }
@@ -685,6 +885,8 @@ inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t 
         IVS_DENSE_CASE(IVS_CUBIC, "surface_dense_kernel<cubic>")
         IVS_DENSE_CASE(IVS_CUBICSPLINE, "surface_dense_kernel<cubicspline>")
         IVS_DENSE_CASE(IVS_SLINEAR, "surface_dense_kernel<slinear>")
+        IVS_DENSE_CASE(IVS_PCHIP, "surface_dense_kernel<pchip>")
+        IVS_DENSE_CASE(IVS_AKIMA, "surface_dense_kernel<akima>")
         default: return 0;
     }
 #undef IVS_DENSE_CASE

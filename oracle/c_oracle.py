@@ -42,7 +42,7 @@ class _Runner:
                                                Tq.ctypes.data, 0 if Tq.ndim == 1 else mT, mT, out.ctypes.data,
                                                st.ctypes.data, int(method))
         if rc:
-            raise ValueError("C oracle: size beyond NMAX")
+            raise ValueError("C oracle: size beyond NMAX" if rc == -1 else "C oracle: method not restated in C")
         return out, st
 
 

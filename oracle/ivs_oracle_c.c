@@ -5,6 +5,8 @@
  *   pandas _interpolate_1d NaN rules (pandas/core/missing.py:435-546)       -> interp1d()
  *   scipy  not-a-knot slopes (scipy/interpolate/_cubic.py:748-884)          -> nak_slopes()
  *   scipy  PPoly coefficient build + Horner (_cubic.py:170-180)             -> hermite()
+ *   scipy  PchipInterpolator._find_derivatives/_edge_case (_cubic.py:248-309) -> pchip_slopes()
+ *   scipy  Akima1DInterpolator.__init__ (_cubic.py:510-541)                 -> akima_slopes()
  * reached by the reference through Series.interpolate (reference src/interpolation/core.py:61).
  * Pinned by tests/test_c_oracle.py against the NumPy oracle and the reference's golden vectors.
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; contraction off keeps 'linear' bit-equal to numpy)
@@ -17,10 +19,11 @@
 #include <omp.h>
 #endif
 
-enum { LINEAR = 0, CUBIC = 1, CUBICSPLINE = 2, SLINEAR = 3 };
+enum { LINEAR = 0, CUBIC = 1, CUBICSPLINE = 2, SLINEAR = 3, PCHIP = 6, AKIMA = 7 };
 #define NMAX 1024
 
-static int min_knots(int m) { return m == LINEAR ? 0 : (m == CUBIC ? 4 : 2); }
+static int supported(int m) { return m == LINEAR || m == CUBIC || m == CUBICSPLINE || m == SLINEAR || m == PCHIP || m == AKIMA; }
+static int min_knots(int m) { return m == LINEAR ? 0 : (m == CUBIC ? 4 : (m == AKIMA ? 3 : 2)); }
 
 static int interval(const double* x, int n, double xq) { /* largest j with x[j] <= xq, or -1 */
     int lo = 0, hi = n;
@@ -67,6 +70,48 @@ static void nak_slopes(const double* x, const double* y, int n, double* s) {
     for (int i = n - 2; i >= 0; --i) s[i] = dp[i] - cp[i] * s[i + 1];
 }
 
+static double sgn(double v) { return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
+
+static double pchip_edge(double h0, double h1, double m0, double m1) {
+    double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+    if (sgn(d) != sgn(m0)) return 0.0;
+    if (sgn(m0) != sgn(m1) && fabs(d) > 3.0 * fabs(m0)) return 3.0 * m0;
+    return d;
+}
+
+static void pchip_slopes(const double* x, const double* y, int n, double* s) {
+    double hk[NMAX], mk[NMAX];
+    for (int i = 0; i < n - 1; ++i) { hk[i] = x[i + 1] - x[i]; mk[i] = (y[i + 1] - y[i]) / hk[i]; }
+    if (n == 2) { s[0] = s[1] = mk[0]; return; }
+    for (int k = 1; k < n - 1; ++k) {
+        int cond = sgn(mk[k]) != sgn(mk[k - 1]) || mk[k] == 0.0 || mk[k - 1] == 0.0;
+        double w1 = 2.0 * hk[k] + hk[k - 1], w2 = hk[k] + 2.0 * hk[k - 1];
+        double whmean = (w1 / mk[k - 1] + w2 / mk[k]) / (w1 + w2);
+        s[k] = cond ? 0.0 : 1.0 / whmean;
+    }
+    s[0] = pchip_edge(hk[0], hk[1], mk[0], mk[1]);
+    s[n - 1] = pchip_edge(hk[n - 2], hk[n - 3], mk[n - 2], mk[n - 3]);
+}
+
+static void akima_slopes(const double* x, const double* y, int n, double* s) {   /* n >= 3 */
+    double mb[NMAX + 3];
+    double* m = mb;                                   /* m[i + 2] = secant i */
+    for (int i = 0; i < n - 1; ++i) m[i + 2] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+    m[1] = 2.0 * m[2] - m[3];
+    m[0] = 2.0 * m[1] - m[2];
+    m[n + 1] = 2.0 * m[n] - m[n - 1];
+    m[n + 2] = 2.0 * m[n + 1] - m[n];
+    double fmax = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        double f12 = fabs(m[i + 3] - m[i + 2]) + fabs(m[i + 1] - m[i]);
+        if (f12 > fmax) fmax = f12;
+    }
+    for (int i = 0; i < n; ++i) {
+        double f1 = fabs(m[i + 3] - m[i + 2]), f2 = fabs(m[i + 1] - m[i]), f12 = f1 + f2;
+        s[i] = f12 > 1e-9 * fmax ? (f1 * m[i + 1] + f2 * m[i + 2]) / f12 : 0.5 * (m[i + 3] + m[i]);
+    }
+}
+
 static double hermite(const double* x, const double* y, const double* s, int n, double xq, int extrap) {
     int j = interval(x, n, xq);
     if (j < 0) return NAN;
@@ -93,8 +138,11 @@ static int interp1d(const double* xk, const double* yk, int ystride, int n, cons
         for (int q = 0; q < m; ++q) out[(size_t)q * ostride] = lerp(xv, yv, nv, xq[q], method == LINEAR);
         return 0;
     }
-    nak_slopes(xv, yv, nv, s);
-    for (int q = 0; q < m; ++q) out[(size_t)q * ostride] = hermite(xv, yv, s, nv, xq[q], method == CUBICSPLINE);
+    if (method == PCHIP) pchip_slopes(xv, yv, nv, s);
+    else if (method == AKIMA) akima_slopes(xv, yv, nv, s);
+    else nak_slopes(xv, yv, nv, s);
+    for (int q = 0; q < m; ++q)
+        out[(size_t)q * ostride] = hermite(xv, yv, s, nv, xq[q], method == CUBICSPLINE || method == PCHIP);
     return 0;
 }
 
@@ -121,6 +169,7 @@ int ivs_oracle_surface_batch(const double* K, const int64_t* k_off, int64_t k_st
                              int64_t kq_stride, int mK, const double* Tq, int64_t tq_stride, int mT, double* out,
                              int32_t* status, int method) {
     if (nK > NMAX || nT > NMAX || mK > 65536) return -1;
+    if (!supported(method)) return -2;
 #pragma omp parallel
     {
         double* Z = (double*)malloc(sizeof(double) * (size_t)nT * mK);
@@ -149,6 +198,7 @@ int ivs_oracle_interp1d_batch(const double* xk, const double* yk, int64_t yk_str
                               int C, const double* xq, const int64_t* q_off, double* out, int64_t out_stride,
                               int32_t* status, int method) {
     int rc = 0;
+    if (!supported(method)) return -2;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t s = 0; s < S; ++s) {
         int64_t a = knot_off[s], n = knot_off[s + 1] - a, qa = q_off[s], m = q_off[s + 1] - qa;

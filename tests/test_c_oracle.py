@@ -18,7 +18,7 @@ except FileNotFoundError:
     pytest.skip("libivs_oracle.so not built (make -C oracle)", allow_module_level=True)
 
 
-@pytest.mark.parametrize("method", [O.LINEAR, O.CUBIC, O.CUBICSPLINE, O.SLINEAR])
+@pytest.mark.parametrize("method", [O.LINEAR, O.CUBIC, O.CUBICSPLINE, O.SLINEAR, O.PCHIP, O.AKIMA])
 def test_equals_numpy_oracle_dense_and_masked(method):
     Kq, Tq = synth.query_grids(64, 16)
     for nan_frac in (0.0, 0.2):

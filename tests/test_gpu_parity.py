@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
            "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES}
-DENSE_METHODS = ["linear", "cubic", "cubicspline", "slinear"]          # methods with dense fast kernels
+DENSE_METHODS = ["linear", "cubic", "cubicspline", "slinear"]          # methods with dense AND variable-shape fast kernels
+DENSE64_METHODS = DENSE_METHODS + ["pchip", "akima"]                   # methods with a 64x16 dense kernel
 EXACT = ("linear", "nearest", "zero", "from_derivatives")               # bit-exact against the oracle / pandas
 RTOL, ATOL = 1e-11, 1e-12
 CASES = SymbolCases()
@@ -275,7 +276,7 @@ def test_dense_var_config4_grid_and_1M_ragged_properties():
     assert float((out2 - (out * 2.0 + 0.25)).abs().max()) < 1e-11
 
 
-@pytest.mark.parametrize("method", DENSE_METHODS)
+@pytest.mark.parametrize("method", DENSE64_METHODS)
 def test_dense_kernels_edge_shapes_and_grids(method):
     """Dense and variable-shape kernels on awkward sizes: tiny batches, output grids that are not multiples of 64,
     1 / 17 / 64 / 65 query maturities, queries outside the hull on both sides, unsorted Kq (fine) and unsorted Tq
@@ -310,6 +311,29 @@ def test_dense_kernels_edge_shapes_and_grids(method):
         ref, rst = O.surface_batch(Kfull, T, d["sigma"], Kq, Tq, METHODS[method])
         assert np.array_equal(st.cpu().numpy(), rst), (B, nK, mK, mT)
         close(out.cpu().numpy(), ref, method, f"edge B={B} nK={nK} mK={mK} mT={mT} [{engine.last_kernel()}]")
+
+
+@pytest.mark.parametrize("method", ["pchip", "akima", "cubic", "linear"])
+def test_dense_nonsmooth_quotes_with_plateaus(method):
+    """Quotes that are NOT a smooth smile: noise (a sign change of the secant at almost every knot), plateaus (zero
+    secants: pchip's flat rule, akima's equal-weights rule) and monotone ramps, on the dense 64x16 kernel."""
+    from iv_interpolation_amd import engine, synth
+    r = np.random.default_rng(77)
+    B = 600
+    d = synth.numpy_batch(B, 64, 16, seed=5)
+    sig = d["sigma"].copy()
+    sig[:200] = r.uniform(0.05, 1.5, size=(200, 16, 64))                              # noise
+    lv = np.repeat(r.uniform(0.1, 1.0, size=(200, 16, 8)), 8, axis=2)                 # plateaus of 8 strikes
+    sig[200:400] = lv
+    sig[300:400] = np.repeat(r.uniform(0.1, 1.0, size=(100, 2, 64)), 8, axis=1)       # plateaus along maturity
+    sig[400:500] = np.cumsum(r.uniform(0.0, 0.02, size=(100, 16, 64)), axis=2) + 0.1  # monotone in strike
+    sig[500:] = 0.3                                                                   # flat surfaces
+    Kq = np.linspace(0.72, 1.28, 64); Tq = np.linspace(2 / 365, 1.4, 16)
+    out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(sig), dev(Kq), dev(Tq), method)
+    assert engine.last_kernel().startswith("surface_dense_kernel<" + method)
+    ref, rst = O.surface_batch(d["K"], d["T"], sig, Kq, Tq, METHODS[method])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    close(out.cpu().numpy(), ref, method, f"nonsmooth {method}")
 
 
 def test_interpolate_frame_on_gpu_equals_per_symbol():
