@@ -11,7 +11,7 @@
 #include "ivs_greeks.hpp"
 #include "ivs_interp1d.hpp"
 #include "ivs_surface_dense.hpp"
-#include "ivs_surface_dense_var.hpp"
+#include "ivs_surface_dense_var2.hpp"
 #include "ivs_surface_generic.hpp"
 
 namespace {

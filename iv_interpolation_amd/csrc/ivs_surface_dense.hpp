@@ -542,10 +542,11 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
 // strike.  Solves the lane's 16-knot system in registers (cubic) and walks the output rows class by class
 // (left-NaN rows, rows per maturity interval, hold rows, right-NaN rows), storing 512-B rows through a
 // wave-uniform base pointer.
-template <int METHOD, bool WLDS, class StampFn>
+// RANGED: only the output rows [row_lo, row_hi) are produced (two-wavefront kernels split the rows).
+template <int METHOD, bool WLDS, bool RANGED = false, class StampFn>
 __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const TqTables& tt, const double* TT,
                                                     const double* W, double* outb, int q0, int lane, bool act, int mT,
-                                                    int mK, StampFn&& stamp) {
+                                                    int mK, StampFn&& stamp, int row_lo = 0, int row_hi = 0) {
     constexpr bool CUB = d_is_hermite(METHOD);
     constexpr bool w_lds = WLDS;
     const double nanv = __builtin_nan("");
@@ -556,11 +557,16 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         double* rp = outb + (int64_t)row * mK + q0;           // uniform
         if (act) rp[lane] = v;
     };
-    for (int c = 0; c < tt.n_left; ++c, ++tq) put(tq, nanv);
+    auto mine = [&](int row) { return !RANGED || (row >= row_lo && row < row_hi); };      // wave-uniform
+    for (int c = 0; c < tt.n_left; ++c, ++tq) if (mine(tq)) put(tq, nanv);
     // weights of row tq: LDS broadcast (prefetched one row ahead) when mT <= 16, else readlane
     const double2* W2 = reinterpret_cast<const double2*>(W);
     double2 wa_n = double2{0.0, 0.0}, wb_n = double2{0.0, 0.0};
-    if (w_lds) { const int t0 = tq < mT ? tq : 0; wa_n = W2[2 * t0]; wb_n = W2[2 * t0 + 1]; }
+    if (w_lds) {
+        int t0 = tq < mT ? tq : 0;
+        if (RANGED && t0 < row_lo) t0 = row_lo < mT ? row_lo : 0;       // first row this wave will ask for
+        wa_n = W2[2 * t0]; wb_n = W2[2 * t0 + 1];
+    }
     auto weights = [&](int row, double& a0, double& a1, double& a2, double& a3) {
         if (w_lds) {
             a0 = wa_n.x; a1 = wa_n.y; a2 = wb_n.x; a3 = wb_n.y;
@@ -612,6 +618,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
 #pragma unroll
         for (int jv = 0; jv < DT - 1; ++jv) {
             for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+                if (!mine(tq)) continue;
                 double a0, a1, a2, a3;
                 weights(tq, a0, a1, a2, a3);
                 put(tq, a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1]);
@@ -621,6 +628,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
 #pragma unroll
         for (int jv = 0; jv < DT - 1; ++jv) {
             for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+                if (!mine(tq)) continue;
                 double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
                 weights(tq, xt, t0, t1, rdt);
                 const double dt = t1 - t0;
@@ -633,8 +641,8 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
             }
         }
     }
-    for (int c = 0; c < tt.n_hold; ++c, ++tq) put(tq, z[DT - 1]);
-    for (int c = 0; c < tt.n_nan; ++c, ++tq) put(tq, nanv);
+    for (int c = 0; c < tt.n_hold; ++c, ++tq) if (mine(tq)) put(tq, z[DT - 1]);
+    for (int c = 0; c < tt.n_nan; ++c, ++tq) if (mine(tq)) put(tq, nanv);
 }
 
 template <int METHOD, bool TSHARED, bool WLDS, bool STAMP = false>

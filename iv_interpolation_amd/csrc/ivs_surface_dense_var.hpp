@@ -388,53 +388,4 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
     }
 }
 
-// Dispatch for variable strike counts.  Returns 1 if dispatched (dense var kernel(s) + filtered generic redo pass),
-// 0 if the batch is not covered.
-inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name) {
-    if (p.nT != DT || p.t_stride != 0 || p.tq_stride != 0 || p.mT > D_MAX_MT) return 0;
-    if (p.nK < 4 || p.nK > 128) return 0;
-    if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
-    if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
-    const bool wl = p.mT <= D_WLDS_MAX_MT;
-    const bool need1 = p.k_off ? true : p.nK <= 64;
-    const bool need2 = p.nK > 64;
-    auto grid_for = [&](size_t lds) {
-        int per_cu = (int)((160 * 1024) / lds);
-        per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-        int64_t g = (int64_t)num_cu * per_cu;
-        return g > p.B ? p.B : g;
-    };
-#define IVS_VAR_LAUNCH(M, NKB, LO, HI, TAG)                                                                          \
-    {                                                                                                                \
-        const size_t lds = dense_var_lds_bytes<NKB>(p.mT);                                                           \
-        const int64_t grid = grid_for(lds);                                                                          \
-        static bool attr = false;                                                                                    \
-        if (!attr) {                                                                                                 \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var_kernel<M, NKB, true>));                      \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var_kernel<M, NKB, false>));                     \
-            attr = true;                                                                                             \
-        }                                                                                                            \
-        if (wl) hipLaunchKernelGGL((surface_dense_var_kernel<M, NKB, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
-        else hipLaunchKernelGGL((surface_dense_var_kernel<M, NKB, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);     \
-    }
-#define IVS_VAR_CASE(M, NAME)                                                  \
-    case M:                                                                    \
-        if (need1) IVS_VAR_LAUNCH(M, 1, 4, 64, 1)                              \
-        if (need2) IVS_VAR_LAUNCH(M, 2, 65, 128, need1 ? 0 : 1)                \
-        *name = NAME;                                                          \
-        break;
-    switch (p.method) {
-        IVS_VAR_CASE(IVS_LINEAR, "surface_dense_var_kernel<linear>")
-        IVS_VAR_CASE(IVS_CUBIC, "surface_dense_var_kernel<cubic>")
-        IVS_VAR_CASE(IVS_CUBICSPLINE, "surface_dense_var_kernel<cubicspline>")
-        IVS_VAR_CASE(IVS_SLINEAR, "surface_dense_var_kernel<slinear>")
-        default: return 0;
-    }
-#undef IVS_VAR_CASE
-#undef IVS_VAR_LAUNCH
-    if (hipGetLastError() != hipSuccess) return -1;
-    launch_surface_generic<true>(p, num_cu, st);
-    return 1;
-}
-
 }  // namespace ivs
