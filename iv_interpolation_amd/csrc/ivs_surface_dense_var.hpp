@@ -204,10 +204,13 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
     __syncthreads();                                           // table reads done: the S plane may be overwritten
 #pragma unroll
     for (int u = 0; u < NKB; ++u) {
+        // all 16 slots of the segment are written (b128, conflict-free); those beyond n are never read
         double* srow = S + rs_t * RS + 18 * (rs_seg + 4 * u);
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
-            if (m < len[u]) srow[m] = d[u][m];
+        for (int c = 0; c < 8; ++c) {
+            double2 v; v.x = d[u][2 * c]; v.y = d[u][2 * c + 1];
+            *reinterpret_cast<double2*>(srow + 2 * c) = v;
+        }
     }
 }
 

@@ -19,6 +19,11 @@
 namespace ivs {
 
 constexpr int V2_RS = 144;                     // row stride of the Y / S planes (8 segments x 18)
+// 144 doubles = 288 words = 32 (mod 64 banks): rows t and t+2 would share banks in the rs-lane accesses (16 lanes =
+// 4 rows x 4 segments per pass).  Every second pair of rows is pushed 8 doubles further: the four rows of a pass sit
+// at bank offsets {0, 32, 16, 48} + const.
+__device__ __forceinline__ int v2_row(int t) { return t * V2_RS + 8 * (t >> 1); }
+constexpr int V2_PLANE = DT * V2_RS + 64;
 constexpr int V2_XCH = 64;                     // doubles in the exchange area
 // exchange slots
 constexpr int X_MAT = 0;                       // [0..3] wave 0's matrix product
@@ -27,7 +32,7 @@ constexpr int X_BWD = 24;                      // [24..39] backward carry of row
 constexpr int X_BAD = 40;                      // [40..41] NaN flag of wave w
 
 __host__ __device__ inline size_t dense_var2_lds_bytes(int mT) {
-    return (size_t)(2 * DT * V2_RS + 128 + 128 + 64 + V2_XCH + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
+    return (size_t)(2 * V2_PLANE + 128 + 64 + V2_XCH + (mT <= D_WLDS_MAX_MT ? 4 * D_WLDS_MAX_MT : 0)) * 8;
 }
 
 // K-phase of wave w (strike block w).  n in 65..128, so knot 63 is always an interior row and wave 1 can rebuild
@@ -35,7 +40,7 @@ __host__ __device__ inline size_t dense_var2_lds_bytes(int mT) {
 // total of block 0 has to be handed over.
 __device__ __forceinline__ void factor_tables_var2(const double* X, int n, int lane, int w, double* AL, double* CP,
                                                    double* PP, double* QQ, double* PM, double* PI, double* PSI,
-                                                   double* RDX, double* XCH) {
+                                                   double* XCH) {
     const int ir = w * 64 + lane;
     const bool in = ir < n;
     const int i = in ? ir : n - 1;
@@ -99,13 +104,12 @@ __device__ __forceinline__ void factor_tables_var2(const double* X, int n, int l
     if (in) {
         const int kl = d_sl(ir);
         AL[kl] = al; CP[kl] = cp; PP[kl] = pp; QQ[kl] = qq; PM[kl] = pm; PI[kl] = pi; PSI[kl] = psi;
-        RDX[ir] = rdxc;
     }
 }
 
 // Slopes of all 16 rows, run-time n in 65..128; wave w owns the logical segments 4w .. 4w+3.
-__device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double* S, const double* Ksh, double* RDX,
-                                                         double* XCH, int n, int lane, int w) {
+__device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double* S, const double* Ksh, double* XCH,
+                                                         int n, int lane, int w) {
     constexpr int RS = V2_RS;
     double* AL = S;
     double* CP = S + RS;
@@ -114,12 +118,12 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
     double* PM = S + 4 * RS;
     double* PI = S + 5 * RS;
     double* PSI = S + 6 * RS;
-    factor_tables_var2(Ksh, n, lane, w, AL, CP, PP, QQ, PM, PI, PSI, RDX, XCH);
+    factor_tables_var2(Ksh, n, lane, w, AL, CP, PP, QQ, PM, PI, PSI, XCH);
     __syncthreads();
     const int rs_t = lane >> 2, rs_seg = lane & 3;
     const int sg = rs_seg + 4 * w, kb = 16 * sg, kp = 18 * sg;
     int ln = n - kb; ln = ln < 0 ? 0 : (ln > 16 ? 16 : ln);
-    const double* yrow = Y + rs_t * RS;
+    const double* yrow = Y + v2_row(rs_t);
     double d[16];
     double endv, pie;
     {   // ---- local forward sweep
@@ -204,10 +208,13 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
     for (int m = 0; m < 16; ++m)
         if (m < ln) d[m] = d[m] + PSI[kp + m] * sin_;
     __syncthreads();                                           // table reads done: the S plane may be overwritten
-    double* srow = S + rs_t * RS + kp;
+    // all 16 slots of the segment are written (b128, conflict-free); those beyond n are never read
+    double* srow = S + v2_row(rs_t) + kp;
 #pragma unroll
-    for (int m = 0; m < 16; ++m)
-        if (m < ln) srow[m] = d[m];
+    for (int c = 0; c < 8; ++c) {
+        double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
+        *reinterpret_cast<double2*>(srow + 2 * c) = v;
+    }
 }
 
 template <int METHOD, bool WLDS>
@@ -219,10 +226,9 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave index, scalar
     const int mT = p.mT, mK = p.mK;
     double* Y = reinterpret_cast<double*>(smem);
-    double* S = Y + DT * RS;
-    double* Ksh = S + DT * RS;             // 128 entries; strikes beyond n are +inf
-    double* RDX = Ksh + 128;
-    double* TT = RDX + 128;
+    double* S = Y + V2_PLANE;
+    double* Ksh = S + V2_PLANE;            // 128 entries; strikes beyond n are +inf
+    double* TT = Ksh + 128;
     double* XCH = TT + 64;
     double* W = XCH + V2_XCH;
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         unsigned long long bad = 0ull;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-            Y[t * RS + d_sl(w * 64 + lane)] = pre[t];
+            Y[v2_row(t) + d_sl(w * 64 + lane)] = pre[t];
             bad |= __ballot(pre[t] != pre[t]);
         }
         Ksh[w * 64 + lane] = pre_k;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
             tag(b);
         } else {
             if (CUB) {
-                dense_strike_slopes_var2(Y, S, Ksh, RDX, XCH, n, lane, w);
+                dense_strike_slopes_var2(Y, S, Ksh, XCH, n, lane, w);
                 __syncthreads();
             }
             if (!kq_shared) load_xq(Kqb);
@@ -320,11 +326,11 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                 double z[DT];
                 auto strike_rows = [&](auto NR_TAG, int rbase) {
                     constexpr int NR = decltype(NR_TAG)::value;
-                    const double* Yb = Y + rbase * RS;
-                    const double* Sb = S + rbase * RS;
+                    const double* Yb = Y;
+                    const double* Sb = S;
                     if (CUB) {
                         const bool ok = !left && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
-                        const double u = xq - x0, t = u * RDX[jj], omt = 1.0 - t;
+                        const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;   // no 1/dx table: LDS budget
                         const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
                         const double w1 = t * t * (3.0 - 2.0 * t);
                         const double w2 = u * omt * omt;
@@ -333,14 +339,14 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                         double g0[4], g1[4], g2[4], g3[4];
 #pragma unroll
                         for (int r = 0; r < LA; ++r) {
-                            g0[r] = Yb[r * RS + o0]; g1[r] = Yb[r * RS + o1]; g2[r] = Sb[r * RS + o0]; g3[r] = Sb[r * RS + o1];
+                            g0[r] = Yb[v2_row(rbase + r) + o0]; g1[r] = Yb[v2_row(rbase + r) + o1]; g2[r] = Sb[v2_row(rbase + r) + o0]; g3[r] = Sb[v2_row(rbase + r) + o1];
                         }
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
                             if (r + LA < NR) {
                                 const int nn = r + LA;
-                                g0[nn & 3] = Yb[nn * RS + o0]; g1[nn & 3] = Yb[nn * RS + o1];
-                                g2[nn & 3] = Sb[nn * RS + o0]; g3[nn & 3] = Sb[nn * RS + o1];
+                                g0[nn & 3] = Yb[v2_row(rbase + nn) + o0]; g1[nn & 3] = Yb[v2_row(rbase + nn) + o1];
+                                g2[nn & 3] = Sb[v2_row(rbase + nn) + o0]; g3[nn & 3] = Sb[v2_row(rbase + nn) + o1];
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             z[r] = w0 * g0[r & 3] + w1 * g1[r & 3] + w2 * g2[r & 3] + w3 * g3[r & 3];
@@ -354,10 +360,10 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                         constexpr int LA = 6;
                         double g0[8], g1[8];
 #pragma unroll
-                        for (int r = 0; r < LA; ++r) { g0[r] = Yb[r * RS + o0]; g1[r] = Yb[r * RS + o1]; }
+                        for (int r = 0; r < LA; ++r) { g0[r] = Yb[v2_row(rbase + r) + o0]; g1[r] = Yb[v2_row(rbase + r) + o1]; }
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
-                            if (r + LA < NR) { const int nn = r + LA; g0[nn & 7] = Yb[nn * RS + o0]; g1[nn & 7] = Yb[nn * RS + o1]; }
+                            if (r + LA < NR) { const int nn = r + LA; g0[nn & 7] = Yb[v2_row(rbase + nn) + o0]; g1[nn & 7] = Yb[v2_row(rbase + nn) + o1]; }
                             __builtin_amdgcn_sched_barrier(0);
                             const double y0 = g0[r & 7], y1 = g1[r & 7];
                             double v = lerp_fast(xq, x0, y0, y1, dx, rdx, slow);
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                         if (__builtin_expect(__ballot(slow && !right && !left) != 0ull, 0)) {
                             if (slow && !right && !left) {
 #pragma unroll
-                                for (int r = 0; r < NR; ++r) z[r] = lerp_np(xq, x0, Yb[r * RS + o0], x1, Yb[r * RS + o1]);
+                                for (int r = 0; r < NR; ++r) z[r] = lerp_np(xq, x0, Yb[v2_row(rbase + r) + o0], x1, Yb[v2_row(rbase + r) + o1]);
                             }
                         }
                     }

@@ -8,7 +8,7 @@ from iv_interpolation_amd import _lib, synth
 
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--method", default="cubic")
 ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--batch", type=int, default=1_000_000)
-ap.add_argument("--mk", type=int, default=64); ap.add_argument("--mt", type=int, default=16)
+ap.add_argument("--nk", type=int, default=64); ap.add_argument("--mk", type=int, default=64); ap.add_argument("--mt", type=int, default=16)
 a = ap.parse_args()
 libs = []
 for pth in a.libs:
@@ -16,12 +16,12 @@ for pth in a.libs:
     res, args = _lib.SIGNATURES["ivs_surface_batch_f64"]
     lib.ivs_surface_batch_f64.restype = res; lib.ivs_surface_batch_f64.argtypes = args
     libs.append(lib)
-d = synth.torch_batch(a.batch, 64, 16)
+d = synth.torch_batch(a.batch, a.nk, 16)
 Kq, Tq = synth.query_grids(a.mk, a.mt); Kq = torch.from_numpy(Kq).cuda(); Tq = torch.from_numpy(Tq).cuda()
 out = torch.empty((a.batch, a.mt, a.mk), dtype=torch.float64, device="cuda"); st = torch.empty(a.batch, dtype=torch.int32, device="cuda")
 code = _lib.METHOD_CODES[a.method]
 def run(lib):
-    rc = lib.ivs_surface_batch_f64(d["K"].data_ptr(), None, 64, 64, d["T"].data_ptr(), 0, 16, d["sigma"].data_ptr(), a.batch,
+    rc = lib.ivs_surface_batch_f64(d["K"].data_ptr(), None, a.nk, a.nk, d["T"].data_ptr(), 0, 16, d["sigma"].data_ptr(), a.batch,
                                    Kq.data_ptr(), 0, a.mk, Tq.data_ptr(), 0, a.mt, out.data_ptr(), st.data_ptr(), code, 0,
                                    torch.cuda.current_stream().cuda_stream)
     assert rc == 0

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-end measurement set on the GPU box: full GPU test suite, bench lines for every workload, rocprofv3
+# kernel-trace summaries of the same commands, PMC passes.  Everything lands under gpurun_out/final/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
+tail -1 $O/gpu_tests.log
+python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
+for spec in "cubic cfg3 20" "linear cfg3 20" "pchip cfg3 20" "akima cfg3 20" "cubicspline cfg3 20" "cubic cfg4 10" "linear cfg4 10" "cubic cfg5 5" "linear cfg5 5"; do
+  set -- $spec
+  python bench.py --steps $3 --warmup 2 --method $1 --workload $2 --no-cpu-baseline > $O/bench_$2_$1.json 2> $O/bench_$2_$1.err || { tail -5 $O/bench_$2_$1.err; exit 1; }
+done
+python bench.py --steps 5 --warmup 1 --force-generic --no-cpu-baseline > $O/bench_cfg3_cubic_generic.json 2> $O/bench_generic.err || exit 1
+cd /tmp && export TMPDIR=/tmp
+for spec in "cubic cfg3 20" "linear cfg3 20" "pchip cfg3 20" "cubic cfg4 10" "cubic cfg5 5"; do
+  set -- $spec
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$2_$1 -- python3 $R/bench.py --steps $3 --warmup 2 --method $1 --workload $2 --no-cpu-baseline --check 0 > $O/bench_$2_$1_under_rocprof.json 2> $O/trace_$2_$1.err || { tail -5 $O/trace_$2_$1.err; exit 1; }
+  f=$(find $O/trace_$2_$1 -name '*kernel_stats.csv' | head -1)
+  cp "$f" $O/kernel_stats_$2_$1.csv
+done
+cd $R
+bash tools/pmc_run.sh cubic --steps 5 --warmup 1 > $O/pmc_cubic.txt 2>&1 || { tail -5 $O/pmc_cubic.txt; exit 1; }
+bash tools/pmc_run.sh cfg5 --steps 3 --warmup 1 --workload cfg5 > $O/pmc_cfg5.txt 2>&1 || { tail -5 $O/pmc_cfg5.txt; exit 1; }
+python - <<'PY'
+import json,glob,os
+O=os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"),"gpurun_out/final")
+for f in sorted(glob.glob(O+"/bench_*.json")):
+    try: d=json.loads(open(f).read())
+    except Exception as e: print(f, "unreadable", e); continue
+    print(os.path.basename(f), "%.1fM surf/s"%(d["value"]/1e6), "%.3f ms"%d["roofline"]["kernel_ms_avg"], "%.0f GB/s frac %.3f"%(d["roofline"]["achieved"], d["roofline"]["frac"]), d["roofline"].get("kernel"))
+PY
