@@ -139,6 +139,32 @@ int ivs_candle_aggregate_f64(const int64_t* ts_ns, const double* open, const dou
                              int64_t n_rows, int64_t freq_ns, int64_t* out_ts, double* out_open, double* out_high,
                              double* out_low, double* out_close, double* out_volume, int32_t* out_count, void* stream);
 
+/*
+ * IV -> OHLCV bridge (reference src/data_bridge/ohlcv_converter.py:138-369, InterpolatedToOHLCVConverter.
+ * _generate_ohlcv_from_interpolated and its four candle builders).  The reference draws from NumPy's process-global
+ * legacy generator; its numbers are reproduced by consuming the SAME MT19937 stream in the same order.
+ *
+ * ivs_mt19937_words_u32: the first n_words raw 32-bit outputs of np.random.seed(seed) into words (device).
+ *
+ * ivs_bridge_candles_f64: S symbols (CSR row_off [S+1]) over total_rows interpolated rows, processed in row order like
+ * the reference's sequential loops.  price [total_rows] = the selected price column, volume [total_rows] or NULL
+ * (column absent).  strategy: 0 spread_simulation (:209-263; base_spread_pct / vol_factor = its spread_parameters),
+ * 1 price_as_midpoint (:265-290), 2 trend_following (:292-332), 3 simple_spread (:334-357, also the reference's
+ * fallback for unknown names), 4 the inline variant of CompleteOptimizedPipeline._generate_ohlcv_candles (reference
+ * complete_pipeline.py:473-510; price = its per-row `underlying or mark or index` choice, made by the caller).  words [n_words]: the stream positioned at this call's first draw.
+ * out [6][total_rows]: open, high, low, close (Python round(x, 4)), volume (round(x, 6)), source_price; rows the
+ * reference skips (price NaN or <= 0, :156-157) get valid = 0 and NaN.  rng_tail (device int64[4]):
+ * [0] out: words consumed; [1],[2] in/out: the legacy generator's cached normal deviate (has_gauss, gauss bits; pass
+ * zeros after a fresh seed); [3] out: 1 if n_words was too small (results invalid: regenerate more words and retry).
+ * workspace: ivs_bridge_workspace_bytes(total_rows) bytes of device scratch.
+ */
+size_t  ivs_bridge_workspace_bytes(int64_t total_rows);
+int     ivs_mt19937_words_u32(uint32_t seed, uint32_t* words, int64_t n_words, void* stream);
+int     ivs_bridge_candles_f64(const double* price, const double* volume, const int64_t* row_off, int64_t S,
+                               int64_t total_rows, int32_t strategy, double base_spread_pct, double vol_factor,
+                               const uint32_t* words, int64_t n_words, double* out, uint8_t* valid, int64_t* rng_tail,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* name of the kernel the last ivs_surface_batch_f64 call on this thread dispatched to (host string) */
 const char* ivs_last_kernel(void);
 

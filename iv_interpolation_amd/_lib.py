@@ -47,6 +47,10 @@ SIGNATURES = {
     "ivs_ffill_index_batch": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _i64, _p, _i64, _p]),
     "ivs_bs_greeks_f64": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "ivs_candle_aggregate_f64": (C.c_int, [_p] * 7 + [_i64, _i64, _i64] + [_p] * 8),
+    "ivs_bridge_workspace_bytes": (C.c_size_t, [_i64]),
+    "ivs_mt19937_words_u32": (C.c_int, [C.c_uint32, _p, _i64, _p]),
+    "ivs_bridge_candles_f64": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, C.c_double, C.c_double, _p, _i64, _p, _p, _p,
+                                         _p, C.c_size_t, _p]),
     "ivs_debug_stamps": (C.c_int, [_p, _i64]),
     "ivs_debug_last_grid": (_i64, []),
     "ivs_surface_batch_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i32,

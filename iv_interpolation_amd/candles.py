@@ -14,10 +14,21 @@ logger = logging.getLogger("candle_reconstruction.core")
 COLUMN_ORDER = ["symbol", "timestamp", "open", "high", "low", "close", "volume", "frequency", "source_candles", "created_at"]
 
 
+class HipCandleBackend:
+    """Packed host columns -> device -> sparse per-row result of ivs_candle_aggregate_f64 (see engine.candle_aggregate)."""
+
+    def candle_aggregate(self, ts, cols, off, minutes):
+        torch = engine.require_device()
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+        out = engine.candle_aggregate(dev(ts), *[dev(c) for c in cols], dev(off), minutes)
+        return [t.cpu().numpy() for t in out]
+
+
 class CandleReconstructor:
-    def __init__(self, target_frequency: str = "5min"):
+    def __init__(self, target_frequency: str = "5min", backend=None):
         self.target_frequency = target_frequency
         self.frequency_minutes = self._parse_frequency(target_frequency)
+        self._backend = backend          # None -> HipCandleBackend on first use
 
     def _parse_frequency(self, freq: str) -> int:
         if freq.endswith("min"):
@@ -30,7 +41,6 @@ class CandleReconstructor:
         return self.reconstruct_batch([minute_data])[0]
 
     def reconstruct_batch(self, frames: Sequence[pd.DataFrame]) -> List[Optional[pd.DataFrame]]:
-        torch = engine.require_device()
         res: List[Optional[pd.DataFrame]] = [None] * len(frames)
         live, packed = [], []
         for i, f in enumerate(frames):
@@ -52,9 +62,8 @@ class CandleReconstructor:
         off = np.concatenate([[0], np.cumsum([len(d) for d in packed])]).astype(np.int64)
         ts = np.concatenate([pd.DatetimeIndex(d["timestamp"]).as_unit("ns").asi8 for d in packed])
         cols = [np.concatenate([d[c].to_numpy(np.float64) for d in packed]) for c in ("open", "high", "low", "close", "volume")]
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
-        out = engine.candle_aggregate(dev(ts), *[dev(c) for c in cols], dev(off), self.frequency_minutes)
-        out = [t.cpu().numpy() for t in out]
+        be = self._backend or HipCandleBackend()
+        out = be.candle_aggregate(ts, cols, off, self.frequency_minutes)
         cnt = out[6]
         for k, i in enumerate(live):
             a, b = off[k], off[k + 1]

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/ivs.h"
+#include "ivs_bridge.hpp"
 #include "ivs_candles.hpp"
 #include "ivs_greeks.hpp"
 #include "ivs_interp1d.hpp"
@@ -151,6 +152,65 @@ int ivs_candle_aggregate_f64(const int64_t* ts_ns, const double* open, const dou
     hipLaunchKernelGGL(ivs::candle_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p);
     return check_launch("candle_kernel");
+}
+
+size_t ivs_bridge_workspace_bytes(int64_t total_rows) { return ivs::bridge_ws_bytes(total_rows < 0 ? 0 : total_rows); }
+
+int ivs_mt19937_words_u32(uint32_t seed, uint32_t* words, int64_t n_words, void* stream) {
+    g_err[0] = 0;
+    if (n_words < 0) return fail(IVS_EINVAL, "ivs_mt19937_words_u32: negative size");
+    if (n_words == 0) return IVS_OK;
+    if (!words) return fail(IVS_EINVAL, "ivs_mt19937_words_u32: null pointer");
+    hipLaunchKernelGGL(ivs::mt19937_words_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), seed, words, n_words);
+    return check_launch("mt19937_words_kernel");
+}
+
+int ivs_bridge_candles_f64(const double* price, const double* volume, const int64_t* row_off, int64_t S,
+                           int64_t total_rows, int32_t strategy, double base_spread_pct, double vol_factor,
+                           const uint32_t* words, int64_t n_words, double* out, uint8_t* valid, int64_t* rng_tail,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    g_err[0] = 0;
+    if (S < 0 || total_rows < 0 || n_words < 0) return fail(IVS_EINVAL, "ivs_bridge_candles_f64: negative size");
+    if (strategy < 0 || strategy > 4) return fail(IVS_EINVAL, "ivs_bridge_candles_f64: unknown strategy %d", strategy);
+    if (!rng_tail) return fail(IVS_EINVAL, "ivs_bridge_candles_f64: null rng_tail");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (S == 0 || total_rows == 0) {
+        if (hipMemsetAsync(rng_tail, 0, 8, st) != hipSuccess || hipMemsetAsync(rng_tail + 3, 0, 8, st) != hipSuccess)
+            return fail(IVS_ELAUNCH, "ivs_bridge_candles_f64: memset failed");
+        return IVS_OK;
+    }
+    if (!price || !row_off || !words || !out || !valid || !workspace)
+        return fail(IVS_EINVAL, "ivs_bridge_candles_f64: null pointer");
+    if (workspace_bytes < ivs::bridge_ws_bytes(total_rows)) return fail(IVS_ENOMEM, "ivs_bridge_candles_f64: workspace too small");
+    const int64_t nb = ivs::bridge_blocks(total_rows);
+    if (nb > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_bridge_candles_f64: too many rows");
+    auto align64 = [](uintptr_t a) { return (a + 63) & ~(uintptr_t)63; };
+    uintptr_t w = align64(reinterpret_cast<uintptr_t>(workspace));
+    ivs::BridgeParams p;
+    p.price = price; p.volume = volume; p.row_off = row_off; p.S = S; p.total_rows = total_rows;
+    p.strategy = strategy; p.base_spread_pct = base_spread_pct; p.vol_factor = vol_factor;
+    p.words = words; p.n_words = n_words; p.out = out; p.valid = valid; p.rng_tail = rng_tail;
+    p.woff = reinterpret_cast<int32_t*>(w); w = align64(w + (size_t)total_rows * 4);
+    p.bbase = reinterpret_cast<int64_t*>(w); w = align64(w + (size_t)(nb + 1) * 8);
+    p.gauss = reinterpret_cast<double*>(w); w = align64(w + (size_t)total_rows * 8);
+    p.expu = reinterpret_cast<double*>(w);
+    if (hipMemsetAsync(rng_tail + 3, 0, 8, st) != hipSuccess) return fail(IVS_ELAUNCH, "ivs_bridge_candles_f64: memset failed");
+    if (strategy == ivs::BR_TREND) {
+        hipLaunchKernelGGL(ivs::bridge_gauss_kernel, dim3(1), dim3(64), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(ivs::bridge_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(ivs::bridge_scan_blocks_kernel, dim3(1), dim3(256), 0, st, p, nb);
+    }
+    int64_t grid = (int64_t)num_cu() * 8;
+    if (grid > S) grid = S;
+    switch (strategy) {
+        case ivs::BR_SPREAD: hipLaunchKernelGGL(ivs::bridge_candles_kernel<ivs::BR_SPREAD>, dim3((unsigned)grid), dim3(64), 0, st, p); break;
+        case ivs::BR_MIDPOINT: hipLaunchKernelGGL(ivs::bridge_candles_kernel<ivs::BR_MIDPOINT>, dim3((unsigned)grid), dim3(64), 0, st, p); break;
+        case ivs::BR_TREND: hipLaunchKernelGGL(ivs::bridge_candles_kernel<ivs::BR_TREND>, dim3((unsigned)grid), dim3(64), 0, st, p); break;
+        case ivs::BR_PIPELINE: hipLaunchKernelGGL(ivs::bridge_candles_kernel<ivs::BR_PIPELINE>, dim3((unsigned)grid), dim3(64), 0, st, p); break;
+        default: hipLaunchKernelGGL(ivs::bridge_candles_kernel<ivs::BR_SIMPLE>, dim3((unsigned)grid), dim3(64), 0, st, p); break;
+    }
+    return check_launch("bridge_candles_kernel");
 }
 
 int ivs_bs_greeks_f64(const double* S, const double* K, const double* T, const double* r, const double* sigma,

@@ -1,0 +1,354 @@
+// IV -> OHLCV bridge (reference src/data_bridge/ohlcv_converter.py:138-369).
+//
+// The reference builds one synthetic candle per interpolated row from draws of NumPy's process-global legacy
+// generator (MT19937: uniform / normal / exponential), row after row, symbol after symbol.  Reproducing its numbers
+// therefore means reproducing that STREAM: the kernels below consume the same 32-bit words in the same order.
+//   mt19937_words_kernel      the raw stream of np.random.seed(seed): one workgroup, 624-word state in LDS,
+//                             regeneration in four dependent phases of <= 227 independent lanes
+//   bridge_count_kernel       words drawn by every row (0 for skipped rows) + block-local exclusive scan
+//   bridge_scan_blocks_kernel exclusive scan of the block totals (one workgroup)
+//   bridge_gauss_kernel       trend_following only: the polar-method normal deviates have data-dependent stream
+//                             positions (rejection + a cached second deviate), so one wavefront walks the rows in order
+//                             (the words staged through LDS in bulk) and leaves each row's deviate and word offset
+//   bridge_candles_kernel<S>  one wavefront per symbol, 64 rows per step: everything that does not depend on the
+//                             previous candle is lane-parallel; the previous-close chain (spread_simulation,
+//                             trend_following) is walked over the valid lanes with v_readlane broadcasts
+// Arithmetic order follows the reference statement by statement (fp contraction off); Python's round(x, n) on
+// floats (correctly rounded decimal, exact ties to even) is emulated exactly with an FMA residual.
+#pragma once
+#include "ivs_device.hpp"
+
+namespace ivs {
+
+enum { BR_SPREAD = 0, BR_MIDPOINT = 1, BR_TREND = 2, BR_SIMPLE = 3, BR_PIPELINE = 4 };   // 4: complete_pipeline.py:473-510
+
+struct BridgeParams {
+    const double* price; const double* volume; const int64_t* row_off; int64_t S; int64_t total_rows;
+    int strategy; double base_spread_pct; double vol_factor;
+    const uint32_t* words; int64_t n_words;
+    double* out; uint8_t* valid;            // out [6][total_rows]: open, high, low, close, volume, source_price
+    int64_t* rng_tail;                      // [0] words consumed (out), [1] has_gauss (in/out), [2] gauss bits (in/out),
+                                            // [3] set to 1 when the word buffer was too short (out)
+    int32_t* woff; int64_t* bbase; double* gauss; double* expu;   // workspace
+};
+
+constexpr int BR_BLOCK = 1024;              // rows per scan block (256 threads x 4)
+
+__host__ __device__ inline int64_t bridge_blocks(int64_t rows) { return (rows + BR_BLOCK - 1) / BR_BLOCK; }
+__host__ __device__ inline size_t bridge_ws_bytes(int64_t rows) {
+    const size_t nb = (size_t)bridge_blocks(rows) + 1;
+    return (size_t)rows * 4 + 64 + nb * 8 + 64 + 2 * ((size_t)rows * 8 + 64);     // woff, bbase, gauss, expu (+ alignment slack)
+}
+
+// ---------------------------------------------------------------- MT19937 (numpy legacy seeding: init_genrand)
+constexpr int MT_N = 624, MT_M = 397;
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+__global__ __launch_bounds__(256) void mt19937_words_kernel(uint32_t seed, uint32_t* words, int64_t n) {
+    __shared__ uint32_t mt[MT_N];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        uint32_t s = seed;
+        for (int i = 0; i < MT_N; ++i) { mt[i] = s; s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1); }
+    }
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += MT_N) {
+        // phase A: i in [0, 227) reads only old words
+        uint32_t v = 0;
+        if (tid < MT_N - MT_M) v = mt[tid + MT_M] ^ mt_twist(mt[tid], mt[tid + 1]);
+        __syncthreads();
+        if (tid < MT_N - MT_M) mt[tid] = v;
+        __syncthreads();
+        // phase B: i in [227, 454) reads new[i-227] (phase A) and old[i], old[i+1]
+        const int ib = tid + (MT_N - MT_M);
+        if (tid < MT_N - MT_M) v = mt[ib - (MT_N - MT_M)] ^ mt_twist(mt[ib], mt[ib + 1]);
+        __syncthreads();
+        if (tid < MT_N - MT_M) mt[ib] = v;
+        __syncthreads();
+        // phase C: i in [454, 623) reads new[i-227] (phase B) and old[i], old[i+1]
+        const int ic = tid + 2 * (MT_N - MT_M);
+        if (ic < MT_N - 1) v = mt[ic - (MT_N - MT_M)] ^ mt_twist(mt[ic], mt[ic + 1]);
+        __syncthreads();
+        if (ic < MT_N - 1) mt[ic] = v;
+        __syncthreads();
+        // phase D: i = 623 reads new[396], old[623], new[0]
+        if (tid == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_twist(mt[MT_N - 1], mt[0]);
+        __syncthreads();
+        for (int i = tid; i < MT_N; i += 256)
+            if (base + i < n) words[base + i] = mt_temper(mt[i]);
+        __syncthreads();
+    }
+}
+
+// legacy_double: two words -> [0, 1)
+__device__ __forceinline__ double mt_double(uint32_t w0, uint32_t w1) {
+    return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+}
+
+// ---------------------------------------------------------------- helpers
+// Python's round(x, nd) for a float x (floatobject.c double_round: correctly rounded decimal, exact ties to even),
+// p10 = 10^nd.  x * p10 = p + e exactly (FMA residual); only an exact tie of p can be tipped by e.
+__device__ __forceinline__ double py_round(double x, double p10) {
+#pragma clang fp contract(off)
+    if (!(__builtin_fabs(x) < __builtin_inf())) return x;
+    const double p = x * p10;
+    const double e = __builtin_fma(x, p10, -p);
+    double r = __builtin_rint(p);
+    const double t = p - r;
+    if (t == 0.5 && e > 0.0) r += 1.0;
+    if (t == -0.5 && e < 0.0) r -= 1.0;
+    return r / p10;
+}
+__device__ __forceinline__ bool row_valid(double base) { return !(__builtin_isnan(base) || base <= 0.0); }   // :156-157
+__device__ __forceinline__ bool vol_missing(double v) { return __builtin_isnan(v) || v <= 0.0; }             // :364
+
+__host__ __device__ inline int bridge_uniforms(int strategy) {      // doubles drawn by the candle builder itself
+    return strategy == BR_SPREAD ? 5 : (strategy == BR_PIPELINE ? 4 : (strategy == BR_MIDPOINT ? 2 : (strategy == BR_SIMPLE ? 1 : 0)));
+}
+
+// ---------------------------------------------------------------- per-row word counts + scan
+__global__ __launch_bounds__(256) void bridge_count_kernel(BridgeParams p) {
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * BR_BLOCK + tid * 4;
+    const int per_row = 2 * bridge_uniforms(p.strategy);
+    int c[4]; int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + k;
+        int n = 0;
+        if (r < p.total_rows && row_valid(p.price[r])) n = per_row + ((p.volume == nullptr || vol_missing(p.volume[r])) ? 2 : 0);
+        c[k] = n; tot += n;
+    }
+    // exclusive scan of the 256 thread totals
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pre = 0, all = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) pre += wsum[w]; all += wsum[w]; }
+    int run = pre + incl - tot;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (r0 + k < p.total_rows) p.woff[r0 + k] = run; run += c[k]; }
+    if (tid == 0) p.bbase[blockIdx.x] = all;        // block total; turned into an exclusive prefix by the next kernel
+}
+
+__global__ __launch_bounds__(256) void bridge_scan_blocks_kernel(BridgeParams p, int64_t nblocks) {
+    __shared__ int64_t wsum[4];
+    __shared__ int64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nblocks; b0 += 256) {
+        const int64_t b = b0 + tid;
+        const int64_t v = b < nblocks ? p.bbase[b] : 0;
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int64_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int64_t pre = carry_s, all = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) pre += wsum[w]; all += wsum[w]; }
+        if (b < nblocks) p.bbase[b] = pre + incl - v;
+        __syncthreads();
+        if (tid == 0) carry_s += all;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.bbase[nblocks] = carry_s;
+        p.rng_tail[0] = carry_s;                     // words consumed; the gauss cache is untouched by these strategies
+        if (carry_s > p.n_words) p.rng_tail[3] = 1;
+    }
+}
+
+// ---------------------------------------------------------------- trend_following: serial deviates
+constexpr int GW_WIN = 8192;                          // words staged per refill
+
+__global__ __launch_bounds__(64) void bridge_gauss_kernel(BridgeParams p) {
+#pragma clang fp contract(off)
+    __shared__ uint32_t win[GW_WIN];
+    const int lane = threadIdx.x;
+    int64_t pos = 0;                                  // absolute word position of the next draw
+    int64_t win_base = 0, win_end = 0;                // [win_base, win_end) staged
+    bool overflow = false;
+    auto need = [&](int k) {                          // make words pos .. pos+k-1 available (uniform call)
+        if (pos + k <= win_end) return;
+        win_base = pos;
+        __syncthreads();
+        for (int i = lane; i < GW_WIN; i += 64) win[i] = (win_base + i < p.n_words) ? p.words[win_base + i] : 0u;
+        __syncthreads();
+        win_end = win_base + GW_WIN;
+        if (pos + k > p.n_words) overflow = true;
+    };
+    auto next_double = [&]() {
+        need(2);
+        const double d = mt_double(win[pos - win_base], win[pos - win_base + 1]);
+        pos += 2;
+        return d;
+    };
+    bool has = p.rng_tail[1] != 0;
+    double cached = __longlong_as_double(p.rng_tail[2]);
+    for (int64_t r0 = 0; r0 < p.total_rows; r0 += 64) {
+        const int64_t r = r0 + lane;
+        const double base = r < p.total_rows ? p.price[r] : __builtin_nan("");
+        const double vol = (p.volume && r < p.total_rows) ? p.volume[r] : 0.0;
+        unsigned long long vm = __ballot(row_valid(base));
+        const unsigned long long em = __ballot(p.volume == nullptr || vol_missing(vol));
+        while (vm) {
+            const int l = __builtin_ctzll(vm);
+            vm &= vm - 1ull;
+            double g;
+            if (has) { g = cached; has = false; cached = 0.0; }
+            else {
+                double x1, x2, r2;
+                do {
+                    x1 = 2.0 * next_double() - 1.0;
+                    x2 = 2.0 * next_double() - 1.0;
+                    r2 = x1 * x1 + x2 * x2;
+                } while ((r2 >= 1.0 || r2 == 0.0) && !overflow);
+                const double f = __builtin_sqrt(-2.0 * __ocml_log_f64(r2) / r2);
+                cached = f * x1; has = true;
+                g = f * x2;
+            }
+            const bool e = (em >> l) & 1ull;
+            double eu = 0.0;
+            if (e) eu = next_double();                   // the row's exponential draw follows its normal draw
+            if (lane == 0) { p.gauss[r0 + l] = g; p.expu[r0 + l] = eu; }
+        }
+    }
+    if (lane == 0) {
+        p.rng_tail[0] = pos; p.rng_tail[1] = has ? 1 : 0; p.rng_tail[2] = __double_as_longlong(cached);
+        if (overflow || pos > p.n_words) p.rng_tail[3] = 1;
+    }
+}
+
+// ---------------------------------------------------------------- candles
+__device__ __forceinline__ double rl_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+template <int STRAT>
+__global__ __launch_bounds__(64) void bridge_candles_kernel(BridgeParams p) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    const double nanv = __builtin_nan("");
+    for (int64_t s = blockIdx.x; s < p.S; s += gridDim.x) {
+        const int64_t a = p.row_off[s], b = p.row_off[s + 1];
+        // chain state, identical in every lane
+        bool has_prev = false; double prev = 0.0;                 // spread_simulation: previous rounded close
+        double ring[5] = {0, 0, 0, 0, 0}; int cnt = 0;            // trend_following: last five rounded closes (ring[4] newest)
+        for (int64_t c0 = a; c0 < b; c0 += 64) {
+            const int64_t row = c0 + lane;
+            const bool in = row < b;
+            const double base = in ? p.price[row] : nanv;
+            const double vol = (in && p.volume) ? p.volume[row] : 0.0;
+            const bool valid = in && row_valid(base);
+            const bool vmiss = p.volume == nullptr || vol_missing(vol);
+            const int64_t w = (valid && STRAT != BR_TREND) ? p.bbase[row >> 10] + (int64_t)p.woff[row] : 0;
+            auto U = [&](int k) {                                  // k-th double of this row's draws
+                if (STRAT == BR_TREND) return valid ? p.expu[row] : 0.0;      // only the exponential draw, left by the walker
+                if (!valid || w + 2 * k + 1 >= p.n_words) return 0.0;
+                return mt_double(p.words[w + 2 * k], p.words[w + 2 * k + 1]);
+            };
+            auto uniform = [](double lo, double hi, double d) { return lo + (hi - lo) * d; };
+            double o = nanv, h = nanv, lw = nanv, c = nanv;
+            double spread = 0.0, uo = 0.0, uc = 0.0, noise = 0.0;
+            constexpr int NU = STRAT == BR_SPREAD ? 5 : (STRAT == BR_PIPELINE ? 4 : (STRAT == BR_MIDPOINT ? 2 : (STRAT == BR_SIMPLE ? 1 : 0)));
+            if (STRAT == BR_SPREAD) {                              // ohlcv_converter.py:209-231
+                const double vmul = uniform(0.5, p.vol_factor, U(0));
+                spread = base * p.base_spread_pct * vmul;
+                uo = uniform(-spread / 3, spread / 3, U(1));
+                uc = uniform(-spread / 3, spread / 3, U(2));
+            } else if (STRAT == BR_TREND) {
+                noise = 0.0 + (base * 0.001) * (valid ? p.gauss[row] : 0.0);          // normal(0, sd) = loc + scale * gauss
+            }
+            // ---- the chain over the valid rows of this chunk (uniform loop, state replicated in all lanes)
+            double tb = 0.0, trend = 0.0;
+            if (STRAT == BR_SPREAD || STRAT == BR_TREND) {
+                unsigned long long m = __ballot(valid);
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const double bl = rl_f64(base, l);
+                    if (STRAT == BR_SPREAD) {
+                        const double tbl = has_prev ? (bl - prev) * 0.3 : 0.0;         // :225-228
+                        const double cl = bl + (rl_f64(uc, l) + tbl * 0.5);             // :234-235
+                        prev = py_round(cl, 1e4); has_prev = true;
+                        if (lane == l) tb = tbl;
+                    } else {
+                        const int lookback = cnt < 5 ? cnt : 5;                         // :296-302
+                        double tr = 0.0;
+                        if (lookback > 1) {
+                            const double first = lookback == 5 ? ring[0] : (lookback == 4 ? ring[1] : (lookback == 3 ? ring[2] : ring[3]));
+                            tr = (ring[4] - first) / (double)lookback;
+                        }
+                        const double cl = bl + tr * 0.6 * 1.2 + rl_f64(noise, l);       // :309
+                        ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3]; ring[3] = ring[4];
+                        ring[4] = py_round(cl, 1e4);
+                        cnt += 1;
+                        if (lane == l) trend = tr;
+                    }
+                }
+            }
+            // ---- lane-parallel completion
+            if (STRAT == BR_SPREAD) {
+                o = base + (uo + tb * 0.2);
+                c = base + (uc + tb * 0.5);
+                const double mid = (o + c) / 2;
+                const double he = uniform(0.0, spread / 2, U(3));
+                const double lr = uniform(0.0, spread / 2, U(4));
+                h = (c > o ? c : o) + he;
+                lw = (c < o ? c : o) - lr;
+                if (h - lw < base * 0.0005) { h = mid + base * 0.00025; lw = mid - base * 0.00025; }
+            } else if (STRAT == BR_MIDPOINT) {                     // :265-275
+                const double sp = base * 0.001;
+                o = base + uniform(-sp / 4, sp / 4, U(0));
+                c = base + uniform(-sp / 4, sp / 4, U(1));
+                h = base + sp / 2; lw = base - sp / 2;
+            } else if (STRAT == BR_TREND) {                        // :304-318
+                o = base + trend * 0.6 + noise;
+                c = base + trend * 0.6 * 1.2 + noise;
+                const double at = __builtin_fabs(trend);
+                const double mx = c > o ? c : o, mn = c < o ? c : o;
+                if (trend > 0) { h = mx + at * 0.5; lw = mn - at * 0.2; }
+                else { h = mx + at * 0.2; lw = mn - at * 0.5; }
+            } else if (STRAT == BR_PIPELINE) {                     // complete_pipeline.py:484-494
+                const double sp = base * 0.001;
+                o = base + uniform(-sp / 3, sp / 3, U(0));
+                c = base + uniform(-sp / 3, sp / 3, U(1));
+                h = (c > o ? c : o) + __builtin_fabs(uniform(0.0, sp / 2, U(2)));
+                lw = (c < o ? c : o) - __builtin_fabs(uniform(0.0, sp / 2, U(3)));
+            } else {                                               // :334-343
+                const double sp = base * 0.001;
+                o = base;
+                c = base + uniform(-sp / 2, sp / 2, U(0));
+                h = base + sp / 2; lw = base - sp / 2;
+            }
+            double v = vol;                                        // :359-369
+            if (vmiss) v = 50.0 * (-__ocml_log_f64(1.0 - U(NU)));
+            v = v > 0.0 ? v : 0.0;
+            if (in) {
+                const int64_t n = p.total_rows;
+                p.valid[row] = valid ? 1 : 0;
+                p.out[row] = valid ? py_round(o, 1e4) : nanv;
+                p.out[n + row] = valid ? py_round(h, 1e4) : nanv;
+                p.out[2 * n + row] = valid ? py_round(lw, 1e4) : nanv;
+                p.out[3 * n + row] = valid ? py_round(c, 1e4) : nanv;
+                p.out[4 * n + row] = valid ? py_round(v, 1e6) : nanv;
+                p.out[5 * n + row] = valid ? base : nanv;
+            }
+        }
+    }
+}
+
+}  // namespace ivs

@@ -220,7 +220,6 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
 template <int METHOD, bool WLDS>
 __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
     constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
-    constexpr int RS = V2_RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave index, scalar

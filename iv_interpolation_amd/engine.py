@@ -153,3 +153,53 @@ def candle_aggregate(ts_ns, o, h, l, c, v, series_off, freq_minutes: int, stream
                                       _stream(torch, stream))
     _lib.check(rc, "ivs_candle_aggregate_f64")
     return (out_ts, *outs, cnt)
+
+
+BRIDGE_STRATEGIES = {"spread_simulation": 0, "price_as_midpoint": 1, "trend_following": 2, "simple_spread": 3,
+                     "pipeline_inline": 4}
+
+
+def mt19937_words(seed: int, n_words: int, device=None, stream=None):
+    """The first n_words raw 32-bit outputs of ``np.random.seed(seed)`` as an int32 CUDA tensor (bit pattern of uint32)."""
+    torch = require_device()
+    lib = _lib.load()
+    if not 0 <= int(seed) <= 0xFFFFFFFF:
+        raise ValueError("Seed must be between 0 and 2**32 - 1")          # numpy's own message
+    words = torch.empty(int(n_words), dtype=torch.int32, device=device or "cuda")
+    rc = lib.ivs_mt19937_words_u32(int(seed), _ptr(words), int(n_words), _stream(torch, stream))
+    _lib.check(rc, "ivs_mt19937_words_u32")
+    return words
+
+
+def bridge_words_bound(total_rows: int, strategy: int) -> int:
+    """Words that certainly cover one bridge call: exact upper bound for the uniform strategies; for trend_following
+    (rejection sampling) a generous estimate -- the call reports when it was not enough."""
+    per_row = {0: 12, 1: 6, 2: 10, 3: 4, 4: 10}[int(strategy)]
+    return int(total_rows) * per_row + 4096
+
+
+def bridge_candles(price, volume, row_off, strategy: int, words, rng_tail=None, base_spread_pct: float = 0.002,
+                   vol_factor: float = 1.5, stream=None):
+    """IV -> OHLCV candles on the device (see ivs_bridge_candles_f64).  price float64 [n], volume float64 [n] or None,
+    row_off int64 [S+1], words int32 [n_words] (from mt19937_words, positioned at this call's first draw), rng_tail
+    int64 [4] or None (fresh generator).  Returns (out [6, n], valid uint8 [n], rng_tail)."""
+    torch = require_device()
+    lib = _lib.load()
+    price = _f64(torch, price, "price")
+    n = price.numel()
+    S = row_off.numel() - 1
+    if volume is not None:
+        volume = _f64(torch, volume, "volume")
+        if volume.numel() != n:
+            raise ValueError("price and volume must have the same length")
+    if rng_tail is None:
+        rng_tail = torch.zeros(4, dtype=torch.int64, device=price.device)
+    out = torch.empty((6, n), dtype=torch.float64, device=price.device)
+    valid = torch.empty(n, dtype=torch.uint8, device=price.device)
+    wsb = lib.ivs_bridge_workspace_bytes(n)
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=price.device)
+    rc = lib.ivs_bridge_candles_f64(_ptr(price), _ptr(volume), _ptr(row_off), S, n, int(strategy), float(base_spread_pct),
+                                    float(vol_factor), _ptr(words), words.numel(), _ptr(out), _ptr(valid), _ptr(rng_tail),
+                                    _ptr(ws), ws.numel() * 8, _stream(torch, stream))
+    _lib.check(rc, "ivs_bridge_candles_f64")
+    return out, valid, rng_tail

@@ -30,6 +30,8 @@ class FrameStore:
 
     def symbols(self, table: str = SOURCE_TABLE) -> List[str]:
         d = os.path.join(self.root, table)
+        if not os.path.isdir(d):
+            return []
         return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".csv"))
 
     def pending_symbols(self) -> List[str]:
@@ -54,6 +56,21 @@ class FrameStore:
     def read_output(self, symbol: str) -> Optional[pd.DataFrame]:
         p = self._path(OUTPUT_TABLE, symbol)
         return pd.read_csv(p, parse_dates=["date"]) if os.path.exists(p) else None
+
+    # downstream tables (minute_candles, reconstructed candles): same per-symbol CSV convention
+    def write_table(self, table: str, symbol: str, df: pd.DataFrame) -> int:
+        os.makedirs(os.path.join(self.root, table), exist_ok=True)
+        df.to_csv(self._path(table, symbol), index=False)
+        return len(df)
+
+    def read_table(self, table: str, symbol: str) -> Optional[pd.DataFrame]:
+        p = self._path(table, symbol)
+        if not os.path.exists(p):
+            return None
+        df = pd.read_csv(p)
+        if "timestamp" in df.columns:
+            df["timestamp"] = pd.to_datetime(df["timestamp"])
+        return df
 
 
 def synthetic_symbol(symbol: str, n_hours: int = 48, seed: int = 0, start: str = "2023-03-01") -> pd.DataFrame:

@@ -1,0 +1,8 @@
+"""Import-path shim for the reference's ``data_bridge.ohlcv_converter`` (MI355X engine underneath)."""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+from iv_interpolation_amd.bridge import InterpolatedToOHLCVConverter  # noqa: E402,F401

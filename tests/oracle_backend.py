@@ -28,3 +28,64 @@ class OracleBackend:
                 r = np.where(last >= 0, prev_valid[np.clip(last, 0, None)], -1)
                 idx[c, q_off[s]:q_off[s + 1]] = np.where(r >= 0, r + a, -1)
         return idx
+
+
+class OracleBridgeBackend:
+    """Test-only stand-in for HipBridgeBackend: the bridge oracle on NumPy's own legacy generator, positioned at
+    word `pos` of the stream of `seed` with the given cached normal deviate."""
+
+    def bridge_candles(self, price, volume, row_off, strategy, seed, pos, tail, base_spread_pct, vol_factor):
+        import bridge_oracle as BO
+        rs = np.random.RandomState(seed)
+        if pos:
+            rs.bytes(4 * pos)
+        st = rs.get_state()
+        rs.set_state((st[0], st[1], st[2], int(tail[0]), float(np.int64(tail[1]).view(np.float64))))
+        total = len(price)
+        valid = np.zeros(total, bool)
+        out = np.full((6, total), np.nan)
+        for s in range(len(row_off) - 1):
+            a, b = int(row_off[s]), int(row_off[s + 1])
+            v, d = BO.candles(price[a:b], volume[a:b], strategy, rs=rs, base_spread_pct=base_spread_pct, vol_factor=vol_factor)
+            valid[a:b] = v
+            idx = a + np.flatnonzero(v)
+            for j, k in enumerate(BO.OUT_COLS):
+                out[j, idx] = d[k]
+        st = rs.get_state()
+        tail_out = (int(st[3]), int(np.float64(st[4]).view(np.int64)))
+        # words consumed: locate the generator's next four words in the stream of `seed`
+        probe = np.random.RandomState(); probe.set_state(st)
+        nxt = np.frombuffer(probe.bytes(16), dtype="<u4")
+        bound = pos + 16 * total + 64
+        while True:
+            w = BO.mt19937_words(seed, bound + 4)
+            hit = np.flatnonzero((w[pos:-3] == nxt[0]) & (w[pos + 1:-2] == nxt[1]) & (w[pos + 2:-1] == nxt[2]) & (w[pos + 3:] == nxt[3]))
+            if len(hit):
+                return out, valid, pos + int(hit[0]), tail_out
+            bound *= 2
+
+
+class OracleCandleBackend:
+    """Test-only stand-in for HipCandleBackend: the sparse per-row layout of ivs_candle_aggregate_f64 from NumPy
+    (bucket heads carry the candle and the group's row count, all other rows count 0)."""
+
+    def candle_aggregate(self, ts, cols, off, minutes):
+        import candles_oracle as CO
+        n = len(ts)
+        f = minutes * 60_000_000_000
+        out_ts = np.zeros(n, np.int64); outs = [np.full(n, np.nan) for _ in range(5)]; cnt = np.zeros(n, np.int32)
+        for s in range(len(off) - 1):
+            a, b = int(off[s]), int(off[s + 1])
+            bucket = (ts[a:b] // f) * f
+            starts = np.flatnonzero(np.r_[True, bucket[1:] != bucket[:-1]]) if b > a else np.zeros(0, np.int64)
+            ends = np.r_[starts[1:], b - a]
+            for i, j in zip(starts, ends):
+                o, h, l, c, v = [x[a + i:a + j] for x in cols]
+                first = o[~np.isnan(o)]; last = c[~np.isnan(c)]
+                out_ts[a + i] = bucket[i]; cnt[a + i] = j - i
+                outs[0][a + i] = first[0] if first.size else np.nan
+                outs[1][a + i] = np.nanmax(h) if (~np.isnan(h)).any() else np.nan
+                outs[2][a + i] = np.nanmin(l) if (~np.isnan(l)).any() else np.nan
+                outs[3][a + i] = last[-1] if last.size else np.nan
+                outs[4][a + i] = CO._kahan_nansum(v)
+        return [out_ts, *outs, cnt]
