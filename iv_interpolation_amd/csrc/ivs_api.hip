@@ -193,10 +193,20 @@ int ivs_bridge_candles_f64(const double* price, const double* volume, const int6
     p.woff = reinterpret_cast<int32_t*>(w); w = align64(w + (size_t)total_rows * 4);
     p.bbase = reinterpret_cast<int64_t*>(w); w = align64(w + (size_t)(nb + 1) * 8);
     p.gauss = reinterpret_cast<double*>(w); w = align64(w + (size_t)total_rows * 8);
-    p.expu = reinterpret_cast<double*>(w);
+    p.expu = reinterpret_cast<double*>(w); w = align64(w + (size_t)total_rows * 8);
+    p.acc = reinterpret_cast<uint8_t*>(w); w = align64(w + ivs::bridge_acc_capacity(total_rows));
+    p.gauss0 = reinterpret_cast<double*>(w);
     if (hipMemsetAsync(rng_tail + 3, 0, 8, st) != hipSuccess) return fail(IVS_ELAUNCH, "ivs_bridge_candles_f64: memset failed");
     if (strategy == ivs::BR_TREND) {
-        hipLaunchKernelGGL(ivs::bridge_gauss_kernel, dim3(1), dim3(64), 0, st, p);
+        int64_t nd = n_words / 2;                                   // doubles of the stream this call may look at
+        const int64_t cap = (int64_t)ivs::bridge_acc_capacity(total_rows);
+        if (nd > cap) { nd = cap; p.n_words = 2 * nd; }
+        int64_t ab = (nd + 255) / 256;
+        const int64_t abcap = (int64_t)num_cu() * 16;
+        if (ab > abcap) ab = abcap;
+        if (ab < 1) ab = 1;
+        hipLaunchKernelGGL(ivs::bridge_accept_kernel, dim3((unsigned)ab), dim3(256), 0, st, p, nd);
+        hipLaunchKernelGGL(ivs::bridge_gauss_walk_kernel, dim3(1), dim3(64), 0, st, p, nd);
     } else {
         hipLaunchKernelGGL(ivs::bridge_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
         hipLaunchKernelGGL(ivs::bridge_scan_blocks_kernel, dim3(1), dim3(256), 0, st, p, nb);

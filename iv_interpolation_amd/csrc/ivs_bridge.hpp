@@ -7,9 +7,11 @@
 //                             regeneration in four dependent phases of <= 227 independent lanes
 //   bridge_count_kernel       words drawn by every row (0 for skipped rows) + block-local exclusive scan
 //   bridge_scan_blocks_kernel exclusive scan of the block totals (one workgroup)
-//   bridge_gauss_kernel       trend_following only: the polar-method normal deviates have data-dependent stream
-//                             positions (rejection + a cached second deviate), so one wavefront walks the rows in order
-//                             (the words staged through LDS in bulk) and leaves each row's deviate and word offset
+//   bridge_accept_kernel /    trend_following only: the polar-method normal deviates have data-dependent stream
+//   bridge_gauss_walk_kernel  positions (rejection + a cached second deviate).  Acceptance of an attempt at every stream
+//                             position is computed in parallel; one wavefront then walks the rows in order doing integer
+//                             work only (next accepted position, flags staged through LDS) and leaves each row the
+//                             position of its attempt; the deviates themselves are computed lane-parallel later
 //   bridge_candles_kernel<S>  one wavefront per symbol, 64 rows per step: everything that does not depend on the
 //                             previous candle is lane-parallel; the previous-close chain (spread_simulation,
 //                             trend_following) is walked over the valid lanes with v_readlane broadcasts
@@ -29,15 +31,18 @@ struct BridgeParams {
     double* out; uint8_t* valid;            // out [6][total_rows]: open, high, low, close, volume, source_price
     int64_t* rng_tail;                      // [0] words consumed (out), [1] has_gauss (in/out), [2] gauss bits (in/out),
                                             // [3] set to 1 when the word buffer was too short (out)
-    int32_t* woff; int64_t* bbase; double* gauss; double* expu;   // workspace
+    int32_t* woff; int64_t* bbase; double* gauss; double* expu; uint8_t* acc; double* gauss0;   // workspace
 };
 
 constexpr int BR_BLOCK = 1024;              // rows per scan block (256 threads x 4)
 
 __host__ __device__ inline int64_t bridge_blocks(int64_t rows) { return (rows + BR_BLOCK - 1) / BR_BLOCK; }
+// doubles of the stream whose polar-method acceptance flag fits in the workspace (trend_following)
+__host__ __device__ inline size_t bridge_acc_capacity(int64_t rows) { return (size_t)rows * 6 + 8192; }
 __host__ __device__ inline size_t bridge_ws_bytes(int64_t rows) {
     const size_t nb = (size_t)bridge_blocks(rows) + 1;
-    return (size_t)rows * 4 + 64 + nb * 8 + 64 + 2 * ((size_t)rows * 8 + 64);     // woff, bbase, gauss, expu (+ alignment slack)
+    // woff, bbase, gauss (gpos), expu (epos), acceptance flags, gauss0 (+ alignment slack)
+    return (size_t)rows * 4 + 64 + nb * 8 + 64 + 2 * ((size_t)rows * 8 + 64) + bridge_acc_capacity(rows) + 64 + 64;
 }
 
 // ---------------------------------------------------------------- MT19937 (numpy legacy seeding: init_genrand)
@@ -169,64 +174,89 @@ __global__ __launch_bounds__(256) void bridge_scan_blocks_kernel(BridgeParams p,
     }
 }
 
-// ---------------------------------------------------------------- trend_following: serial deviates
-constexpr int GW_WIN = 8192;                          // words staged per refill
-
-__global__ __launch_bounds__(64) void bridge_gauss_kernel(BridgeParams p) {
+// ---------------------------------------------------------------- trend_following: where the normal deviates sit
+// legacy_gauss (polar method): an ATTEMPT at double position P uses doubles P, P+1; it is accepted iff
+// 0 < x1^2 + x2^2 < 1; an accepted attempt yields two deviates (f*x2 now, f*x1 cached for the next call).  Whether an
+// attempt is accepted depends on the stream only -> computed for every position in parallel; the order-dependent
+// part that remains is a walk "next accepted position from here", a few integer steps per row.
+__device__ __forceinline__ void polar_pair(const uint32_t* words, int64_t P, double& x1, double& x2, double& r2) {
 #pragma clang fp contract(off)
-    __shared__ uint32_t win[GW_WIN];
+    x1 = 2.0 * mt_double(words[2 * P], words[2 * P + 1]) - 1.0;
+    x2 = 2.0 * mt_double(words[2 * P + 2], words[2 * P + 3]) - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+}
+
+__global__ __launch_bounds__(256) void bridge_accept_kernel(BridgeParams p, int64_t nd) {
+    for (int64_t P = (int64_t)blockIdx.x * 256 + threadIdx.x; P < nd; P += (int64_t)gridDim.x * 256) {
+        uint8_t a = 0;
+        if (P + 1 < nd) { double x1, x2, r2; polar_pair(p.words, P, x1, x2, r2); a = !(r2 >= 1.0 || r2 == 0.0); }
+        p.acc[P] = a;
+    }
+}
+
+constexpr int GW_WIN = 16384;                          // acceptance flags staged per refill
+constexpr int64_t G_CACHED = (int64_t)1 << 62;        // gpos flag: the row takes the cached deviate (f*x1) of that attempt
+constexpr int64_t G_INITIAL = -1;                     // gpos value: the row takes the deviate cached before this call
+
+__global__ __launch_bounds__(64) void bridge_gauss_walk_kernel(BridgeParams p, int64_t nd) {
+#pragma clang fp contract(off)
+    __shared__ uint8_t win[GW_WIN];
     const int lane = threadIdx.x;
-    int64_t pos = 0;                                  // absolute word position of the next draw
-    int64_t win_base = 0, win_end = 0;                // [win_base, win_end) staged
+    int64_t pos = 0;                                  // next draw, in doubles
+    int64_t win_base = 0, win_end = 0;
     bool overflow = false;
-    auto need = [&](int k) {                          // make words pos .. pos+k-1 available (uniform call)
-        if (pos + k <= win_end) return;
-        win_base = pos;
-        __syncthreads();
-        for (int i = lane; i < GW_WIN; i += 64) win[i] = (win_base + i < p.n_words) ? p.words[win_base + i] : 0u;
-        __syncthreads();
-        win_end = win_base + GW_WIN;
-        if (pos + k > p.n_words) overflow = true;
+    auto accepted = [&](int64_t P) -> bool {          // uniform call
+        if (P + 1 >= nd) { overflow = true; return true; }
+        if (P >= win_end) {
+            win_base = P & ~(int64_t)3;                  // keeps the 4-byte loads below aligned
+            __syncthreads();
+            for (int i = lane * 4; i < GW_WIN; i += 256) {
+                uint32_t v = 0;
+                if (win_base + i + 3 < nd) v = *reinterpret_cast<const uint32_t*>(p.acc + win_base + i);
+                else for (int k = 0; k < 4; ++k) if (win_base + i + k < nd) v |= (uint32_t)p.acc[win_base + i + k] << (8 * k);
+                *reinterpret_cast<uint32_t*>(win + i) = v;
+            }
+            __syncthreads();
+            win_end = win_base + GW_WIN;
+        }
+        return win[P - win_base] != 0;
     };
-    auto next_double = [&]() {
-        need(2);
-        const double d = mt_double(win[pos - win_base], win[pos - win_base + 1]);
-        pos += 2;
-        return d;
-    };
+    int64_t* gpos = reinterpret_cast<int64_t*>(p.gauss);
+    int64_t* epos = reinterpret_cast<int64_t*>(p.expu);
     bool has = p.rng_tail[1] != 0;
-    double cached = __longlong_as_double(p.rng_tail[2]);
+    int64_t last = G_INITIAL;                         // attempt whose f*x1 is cached
     for (int64_t r0 = 0; r0 < p.total_rows; r0 += 64) {
         const int64_t r = r0 + lane;
         const double base = r < p.total_rows ? p.price[r] : __builtin_nan("");
         const double vol = (p.volume && r < p.total_rows) ? p.volume[r] : 0.0;
         unsigned long long vm = __ballot(row_valid(base));
         const unsigned long long em = __ballot(p.volume == nullptr || vol_missing(vol));
+        int64_t my_g = 0, my_e = -1;
         while (vm) {
             const int l = __builtin_ctzll(vm);
             vm &= vm - 1ull;
-            double g;
-            if (has) { g = cached; has = false; cached = 0.0; }
+            int64_t g;
+            if (has) { g = last == G_INITIAL ? G_INITIAL : (last | G_CACHED); has = false; }
             else {
-                double x1, x2, r2;
-                do {
-                    x1 = 2.0 * next_double() - 1.0;
-                    x2 = 2.0 * next_double() - 1.0;
-                    r2 = x1 * x1 + x2 * x2;
-                } while ((r2 >= 1.0 || r2 == 0.0) && !overflow);
-                const double f = __builtin_sqrt(-2.0 * __ocml_log_f64(r2) / r2);
-                cached = f * x1; has = true;
-                g = f * x2;
+                while (!accepted(pos)) pos += 2;
+                g = pos; last = pos; pos += 2; has = true;
             }
-            const bool e = (em >> l) & 1ull;
-            double eu = 0.0;
-            if (e) eu = next_double();                   // the row's exponential draw follows its normal draw
-            if (lane == 0) { p.gauss[r0 + l] = g; p.expu[r0 + l] = eu; }
+            int64_t e = -1;
+            if ((em >> l) & 1ull) { e = pos; pos += 1; if (pos > nd) overflow = true; }
+            if (lane == l) { my_g = g; my_e = e; }
         }
+        if (r < p.total_rows) { gpos[r] = my_g; epos[r] = my_e; }        // coalesced; rows that draw nothing are never read
     }
     if (lane == 0) {
-        p.rng_tail[0] = pos; p.rng_tail[1] = has ? 1 : 0; p.rng_tail[2] = __double_as_longlong(cached);
-        if (overflow || pos > p.n_words) p.rng_tail[3] = 1;
+        double cached = __longlong_as_double(p.rng_tail[2]);
+        p.gauss0[0] = cached;                         // the deviate cached BEFORE this call (rows tagged G_INITIAL)
+        if (has && last != G_INITIAL && !overflow) {
+            double x1, x2, r2; polar_pair(p.words, last, x1, x2, r2);
+            cached = __builtin_sqrt(-2.0 * __ocml_log_f64(r2) / r2) * x1;
+        }
+        if (!has) cached = 0.0;
+        p.rng_tail[0] = 2 * pos; p.rng_tail[1] = has ? 1 : 0; p.rng_tail[2] = __double_as_longlong(cached);
+        if (overflow || 2 * pos > p.n_words) p.rng_tail[3] = 1;
     }
 }
 
@@ -256,7 +286,10 @@ __global__ __launch_bounds__(64) void bridge_candles_kernel(BridgeParams p) {
             const bool vmiss = p.volume == nullptr || vol_missing(vol);
             const int64_t w = (valid && STRAT != BR_TREND) ? p.bbase[row >> 10] + (int64_t)p.woff[row] : 0;
             auto U = [&](int k) {                                  // k-th double of this row's draws
-                if (STRAT == BR_TREND) return valid ? p.expu[row] : 0.0;      // only the exponential draw, left by the walker
+                if (STRAT == BR_TREND) {                           // only the exponential draw, at the position left by the walker
+                    const int64_t e = valid ? reinterpret_cast<const int64_t*>(p.expu)[row] : -1;
+                    return (e < 0 || 2 * e + 1 >= p.n_words) ? 0.0 : mt_double(p.words[2 * e], p.words[2 * e + 1]);
+                }
                 if (!valid || w + 2 * k + 1 >= p.n_words) return 0.0;
                 return mt_double(p.words[w + 2 * k], p.words[w + 2 * k + 1]);
             };
@@ -270,7 +303,20 @@ __global__ __launch_bounds__(64) void bridge_candles_kernel(BridgeParams p) {
                 uo = uniform(-spread / 3, spread / 3, U(1));
                 uc = uniform(-spread / 3, spread / 3, U(2));
             } else if (STRAT == BR_TREND) {
-                noise = 0.0 + (base * 0.001) * (valid ? p.gauss[row] : 0.0);          // normal(0, sd) = loc + scale * gauss
+                double g = 0.0;
+                if (valid) {
+                    const int64_t gp = reinterpret_cast<const int64_t*>(p.gauss)[row];
+                    if (gp == G_INITIAL) g = p.gauss0[0];
+                    else {
+                        const int64_t P = gp & ~G_CACHED;
+                        if (2 * P + 3 < p.n_words) {
+                            double x1, x2, r2; polar_pair(p.words, P, x1, x2, r2);
+                            const double f = __builtin_sqrt(-2.0 * __ocml_log_f64(r2) / r2);
+                            g = (gp & G_CACHED) ? f * x1 : f * x2;
+                        }
+                    }
+                }
+                noise = 0.0 + (base * 0.001) * g;                  // normal(0, sd) = loc + scale * gauss
             }
             // ---- the chain over the valid rows of this chunk (uniform loop, state replicated in all lanes)
             double tb = 0.0, trend = 0.0;
