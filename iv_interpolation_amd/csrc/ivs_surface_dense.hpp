@@ -466,24 +466,46 @@ constexpr int D_NSTAMP = 8;   // stage, k-phase, sweeps, strike-eval, maturity-s
 // What the T-phase leaves in registers: per-query-row weights in lane = tq, row counts per class (uniform).
 struct TqTables {
     double w0, w1, w2, w3;
+    double pm_last;                       // run-time nT only: third tap of the last row of the maturity system
     int n_left, n_hold, n_nan, unsorted;
     unsigned long long iv_lo, iv_hi;      // rows per interval 0..7 / 8..14, one byte each
     __device__ __forceinline__ int n_iv(int j) const { return (int)(((j < 8 ? iv_lo : iv_hi) >> (8 * (j & 7))) & 0xffull); }
 };
 
+template <int NKB>
+__device__ __forceinline__ void factor_tables_var(const double* X, int n, int lane, double* AL, double* CP, double* PP,
+                                                  double* QQ, double* PM, double* PI, double* PSI, double* RDX);
+
 // T-phase: maturity-direction factor tables (LDS, TT) + per-query-row weights (registers, lane = tq; also W in LDS
 // when WLDS) + row counts per class.  Needs mT <= 64.  All 64 lanes must call it; ends with a barrier.
-template <int METHOD, bool WLDS>
+// NTR: the maturity count is a run-time value nT_rt in [4, 16] (knots beyond it are +inf, the last system row sits at
+// nT_rt - 1 and uses the three-tap right-hand side of the variable-shape kernels); `scratch` = 8 x 72 doubles of LDS.
+template <int METHOD, bool WLDS, bool NTR = false>
 __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tqb, int mT, int lane, double* Tsh,
-                                              double* TT, double* W, TqTables& tt) {
+                                              double* TT, double* W, TqTables& tt, int nT_rt = DT,
+                                              double* scratch = nullptr) {
+    const int nT = NTR ? nT_rt : DT;
     constexpr bool CUB = d_is_hermite(METHOD);
     constexpr bool w_lds = WLDS;
-    if (lane < DT) Tsh[lane] = Tb[lane];
+    if (lane < DT) Tsh[lane] = (!NTR || lane < nT) ? Tb[lane] : __builtin_inf();
     __syncthreads();
-    if (d_is_nak(METHOD)) {
+    tt.pm_last = 0.0;
+    if (d_is_nak(METHOD) && !NTR) {
         double al, cp, pp, qq, rdx;
         factor_tables<DT>(Tsh, lane, al, cp, pp, qq, rdx);
         if (lane < DT) { TT[lane * 4 + 0] = pp; TT[lane * 4 + 1] = qq; TT[lane * 4 + 2] = al; TT[lane * 4 + 3] = cp; }
+    }
+    if (d_is_nak(METHOD) && NTR) {
+        double* SC = scratch;            // AL, CP, PP, QQ, PM, PI, PSI (72 each, d_sl(i) = i for i < 16) + RDX
+        factor_tables_var<1>(Tsh, nT, lane, SC, SC + 72, SC + 144, SC + 216, SC + 288, SC + 360, SC + 432, SC + 504);
+        __syncthreads();
+        if (lane < DT) {
+            const bool in = lane < nT;
+            TT[lane * 4 + 0] = in ? SC[144 + lane] : 0.0; TT[lane * 4 + 1] = in ? SC[216 + lane] : 0.0;
+            TT[lane * 4 + 2] = in ? SC[lane] : 0.0; TT[lane * 4 + 3] = in ? SC[72 + lane] : 0.0;
+        }
+        tt.pm_last = SC[288 + nT - 1];
+        __syncthreads();
     }
     if (d_is_local(METHOD) && lane < DT) {
         double r0, r1, r2;
@@ -500,15 +522,15 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
         for (int st = 8; st >= 1; st >>= 1) if (Tsh[j + st] <= x) j += st;
     }
     int code;
-    const double tl = Tsh[DT - 1];
+    const double tl = Tsh[nT - 1];
     if (j < 0) code = TQ_LEFT;
-    else if (j >= DT - 1) {
+    else if (j >= nT - 1) {
         if (METHOD == IVS_LINEAR) code = TQ_HOLD;
         else if (METHOD == IVS_SLINEAR) code = (x == tl) ? TQ_HOLD : TQ_NAN;
-        else if (!d_extrap_right(METHOD)) code = (x == tl) ? DT - 2 : TQ_NAN;
-        else code = DT - 2;
+        else if (!d_extrap_right(METHOD)) code = (x == tl) ? nT - 2 : TQ_NAN;
+        else code = nT - 2;
     } else code = j;
-    const int jj = code >= 0 && code <= DT - 2 ? code : 0;
+    const int jj = code >= 0 && code <= nT - 2 ? code : 0;
     const double x0 = Tsh[jj], x1 = Tsh[jj + 1];
     if (CUB) {
         const double h = x1 - x0, u = x - x0, t = u / h, omt = 1.0 - t;
@@ -543,10 +565,13 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
 // (left-NaN rows, rows per maturity interval, hold rows, right-NaN rows), storing 512-B rows through a
 // wave-uniform base pointer.
 // RANGED: only the output rows [row_lo, row_hi) are produced (two-wavefront kernels split the rows).
-template <int METHOD, bool WLDS, bool RANGED = false, class StampFn>
+// NTR: run-time maturity count nT_rt (see dense_t_phase): masked system rows, three-tap last row, hold row = nT_rt - 1.
+template <int METHOD, bool WLDS, bool RANGED = false, bool NTR = false, class StampFn>
 __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const TqTables& tt, const double* TT,
                                                     const double* W, double* outb, int q0, int lane, bool act, int mT,
-                                                    int mK, StampFn&& stamp, int row_lo = 0, int row_hi = 0) {
+                                                    int mK, StampFn&& stamp, int row_lo = 0, int row_hi = 0,
+                                                    int nT_rt = DT) {
+    const int nT = NTR ? nT_rt : DT;
     constexpr bool CUB = d_is_hermite(METHOD);
     constexpr bool w_lds = WLDS;
     const double nanv = __builtin_nan("");
@@ -580,6 +605,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
     if (CUB) {
         double s[DT];
         double prev = 0.0;
+        const double pm_last = NTR ? readlane_f64(tt.pm_last, 0) : 0.0;      // uniform -> SGPRs
         if (d_is_local(METHOD)) {
             dense_maturity_slopes_local<METHOD>(z, TT, s);
             // pin the slopes here: otherwise they (and, transitively, the strike evaluation with its 64 gathered
@@ -603,16 +629,26 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                     tpq[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4);
                     tac[i & 3] = *reinterpret_cast<const double2*>(TT + (i + LA) * 4 + 2);
                 }
-                // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
-                const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
-                const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
-                prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
+                if (!NTR) {
+                    // (dz_{i-1}, dz_i); (dz_0, dz_1) for row 0; (dz_{13}, dz_{14}) for row 15, dz_i = z[i+1] - z[i]
+                    const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                    prev = (pq.x * dA + pq.y * dB) - ac.x * prev;
+                } else {
+                    // three-tap form: PM*dz_{i-2} + PP*dz_{i-1} + QQ*dz_i (PM only on the last row, where QQ = 0).  Rows
+                    // beyond nT have all-zero table entries, so they produce 0 without any masking.
+                    const int ia = i == 0 ? 0 : i - 1, ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                    double r = pq.x * dA + pq.y * dB;
+                    if (i >= 3) r += ((i == nT - 1) ? pm_last : 0.0) * (z[i - 1] - z[i - 2]);     // scalar select
+                    prev = r - ac.x * prev;
+                }
                 s[i] = prev;
                 cpv[i] = ac.y;
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = DT - 2; i >= 0; --i) s[i] = s[i] - cpv[i] * s[i + 1];
+            for (int i = DT - 2; i >= 0; --i) s[i] = s[i] - cpv[i] * s[i + 1];      // CP = 0 from the last row on
         }
         stamp(4);
 #pragma unroll
@@ -641,7 +677,15 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
             }
         }
     }
-    for (int c = 0; c < tt.n_hold; ++c, ++tq) if (mine(tq)) put(tq, z[DT - 1]);
+    double z_last = z[DT - 1];
+    if (NTR) {
+#pragma unroll
+        for (int i = 3; i < DT - 1; ++i) {
+            z_last = (i == nT - 1) ? z[i] : z_last;      // wave-uniform selects
+            asm volatile("" : "+v"(z_last));             // keeps LLVM from turning the chain into z[nT - 1] (= scratch array)
+        }
+    }
+    for (int c = 0; c < tt.n_hold; ++c, ++tq) if (mine(tq)) put(tq, z_last);
     for (int c = 0; c < tt.n_nan; ++c, ++tq) if (mine(tq)) put(tq, nanv);
 }
 

@@ -1,5 +1,6 @@
 // Dense fast path for VARIABLE strike counts: 4 <= nK <= 128 per surface (uniform batches with nK != 64 and
-// ragged CSR batches, BASELINE config 5), 16 maturities, shared T/Tq, no missing quotes.
+// ragged CSR batches, BASELINE config 5), 4..16 maturities (run time, uniform over the batch), shared T/Tq, no missing
+// quotes.
 //
 // Same three-layout scheme as ivs_surface_dense.hpp, with the strike count n a run-time value:
 //   * NKB = 1 handles surfaces with n <= 64, NKB = 2 those with 65..128 (two 64-strike blocks per k-lane, two
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
     auto nostamp = [](int) {};
 
     TqTables tt;
-    dense_t_phase<METHOD, WLDS>(p.T, p.Tq, mT, lane, Y, TT, W, tt);       // shared T/Tq: once per workgroup
+    const int nT = p.nT;                                                   // 4..16, uniform over the batch
+    dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);       // shared T/Tq: once per workgroup
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
     int n = 0, n_next = 0;
     int64_t koff = 0, koff_next = 0;
     auto sigma_of = [&](int64_t b, int64_t ko) -> const double* {
-        return p.k_off ? p.sigma + (int64_t)DT * ko : p.sigma + b * (int64_t)DT * p.nK;
+        return p.k_off ? p.sigma + (int64_t)nT * ko : p.sigma + b * (int64_t)nT * p.nK;
     };
     auto issue_loads = [&](int64_t b, int64_t ko, int nn) {
         const double* sb = sigma_of(b, ko);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
 #pragma unroll
             for (int blk = 0; blk < NKB; ++blk) {
                 const int k = blk * 64 + lane;
-                pre[t * NKB + blk] = k < nn ? sb[(int64_t)t * nn + k] : 0.0;
+                pre[t * NKB + blk] = (t < nT && k < nn) ? sb[(int64_t)t * nn + k] : 0.0;      // rows beyond nT: zeros
             }
 #pragma unroll
         for (int blk = 0; blk < NKB; ++blk) { const int k = blk * 64 + lane; pre_k[blk] = k < nn ? Kb[k] : inf; }
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
                         }
                     }
                 }
-                if (act) dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp);
+                if (act) dense_maturity_pass<METHOD, WLDS, false, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
             }
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         }

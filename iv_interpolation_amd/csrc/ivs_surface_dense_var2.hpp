@@ -234,7 +234,8 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
     auto nostamp = [](int) {};
 
     TqTables tt;
-    dense_t_phase<METHOD, WLDS>(p.T, p.Tq, mT, lane, Y, TT, W, tt);       // both waves write identical tables
+    const int nT = p.nT;                                                   // 4..16, uniform over the batch
+    dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);       // both waves write identical tables
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
@@ -265,10 +266,10 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
     int n = 0, n_next = 0;
     int64_t koff = 0, koff_next = 0;
     auto issue_loads = [&](int64_t b, int64_t ko, int nn) {
-        const double* sb = p.k_off ? p.sigma + (int64_t)DT * ko : p.sigma + b * (int64_t)DT * p.nK;
+        const double* sb = p.k_off ? p.sigma + (int64_t)nT * ko : p.sigma + b * (int64_t)nT * p.nK;
         const int k = w * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < DT; ++t) pre[t] = k < nn ? sb[(int64_t)t * nn + k] : 0.0;
+        for (int t = 0; t < DT; ++t) pre[t] = (t < nT && k < nn) ? sb[(int64_t)t * nn + k] : 0.0;
         pre_k = k < nn ? p.K[ko + k] : inf;
     };
 
@@ -389,11 +390,11 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
 #pragma unroll
                     for (int r = 0; r < DT; ++r) z[r] = ZX[r * 64 + lane];
                     const int half = (mT + 1) >> 1;
-                    if (act) dense_maturity_pass<METHOD, WLDS, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp,
-                                                                     w == 0 ? 0 : half, w == 0 ? half : mT);
+                    if (act) dense_maturity_pass<METHOD, WLDS, true, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp,
+                                                                           w == 0 ? 0 : half, w == 0 ? half : mT, nT);
                 } else {
                     strike_rows(std::integral_constant<int, DT>{}, 0);
-                    if (act) dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp);
+                    if (act) dense_maturity_pass<METHOD, WLDS, false, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
                 }
             }
             if (p.status && threadIdx.x == 0) p.status[b] = IVS_ST_OK;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
 // Dispatch for variable strike counts: class 4..64 on the one-wavefront kernel, class 65..128 on the two-wavefront
 // kernel, then the filtered generic redo pass.  Returns 1 if dispatched, 0 if the batch is not covered.
 inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name) {
-    if (p.nT != DT || p.t_stride != 0 || p.tq_stride != 0 || p.mT > D_MAX_MT) return 0;
+    if (p.nT < 4 || p.nT > DT || p.t_stride != 0 || p.tq_stride != 0 || p.mT > D_MAX_MT) return 0;
     if (p.nK < 4 || p.nK > 128) return 0;
     if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;

@@ -230,6 +230,37 @@ def test_dense_var_uniform_strike_counts(method, nK):
     close(got, ref, method, f"var nK={nK} {method}")
 
 
+@pytest.mark.parametrize("method", DENSE_METHODS)
+@pytest.mark.parametrize("nT", [4, 5, 8, 12, 15])
+def test_dense_var_runtime_maturity_counts(method, nT):
+    """4..16 maturities (run-time value) on the variable-shape kernels: uniform 16 / 64 / 100 strikes and a ragged
+    batch; query maturities on both sides of the hull and on exact knots."""
+    from iv_interpolation_amd import engine, synth
+    T = synth.tenors(nT)
+    Kq = np.linspace(0.68, 1.32, 64)
+    Tq = np.geomspace(0.6 * T[0], 1.3 * T[-1], 16); Tq[3] = T[1]; Tq[-3] = T[-1]; Tq.sort()
+    for nK in (16, 64, 100):
+        d = synth.numpy_batch(257, nK, nT, seed=1000 + 16 * nT + nK)
+        out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method)
+        assert engine.last_kernel().startswith("surface_dense_var_kernel"), engine.last_kernel()
+        ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+        assert np.array_equal(st.cpu().numpy(), rst)
+        close(out.cpu().numpy(), ref, method, f"nT={nT} nK={nK} {method}")
+    d = synth.numpy_ragged_batch(300, nT, 8, 128, seed=77 + nT)
+    out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method,
+                                   k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=nT)
+    assert engine.last_kernel().startswith("surface_dense_var_kernel")
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method], k_off=d["k_off"])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    close(out.cpu().numpy(), ref, method, f"ragged nT={nT} {method}")
+    # wide output grid (two-wavefront kernel alternates query blocks) with more query maturities than weights fit in LDS
+    Kq2 = np.linspace(0.68, 1.32, 200); Tq2 = np.geomspace(0.6 * T[0], 1.3 * T[-1], 40)
+    out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq2), dev(Tq2), method,
+                                   k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=nT)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq2, Tq2, METHODS[method], k_off=d["k_off"])
+    close(out.cpu().numpy(), ref, method, f"ragged wide nT={nT} {method}")
+
+
 @pytest.mark.parametrize("method", ["linear", "cubic"])
 def test_dense_var_ragged_with_nan_and_tiny_surfaces(method):
     """Ragged batch mixing both size classes, surfaces with NaN quotes and surfaces below 4 strikes (generic redo)."""
