@@ -217,7 +217,9 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
 
 struct VarRange { int lo, hi; };   // strike counts served by a launch
 
-template <int METHOD, int NKB, bool WLDS>
+// TSHARED: T and Tq shared by the batch (T-phase once per workgroup); otherwise per surface (t_stride / tq_stride),
+// the T-phase then runs inside the loop with its scratch in the S plane, which is free until the slopes are written.
+template <int METHOD, int NKB, bool WLDS, bool TSHARED = true>
 __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
     constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
     constexpr int RS = NKB * 72;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
 
     TqTables tt;
     const int nT = p.nT;                                                   // 4..16, uniform over the batch
-    dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);       // shared T/Tq: once per workgroup
+    if (TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);       // once per workgroup
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
@@ -303,6 +305,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         double* outb = p.out + b * (int64_t)mT * mK;
         const double* Kqb = p.Kq + b * p.kq_stride;
         const int64_t b_next = seek(b + gridDim.x, n_next, koff_next);
+        if (!TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, S + 600, TT, W,
+                                                        tt, nT, S);
         const bool redo = bad != 0ull || tt.unsorted;
         if (redo) {
             tag(b);

@@ -217,7 +217,7 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
     }
 }
 
-template <int METHOD, bool WLDS>
+template <int METHOD, bool WLDS, bool TSHARED = true>
 __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
     constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
 
     TqTables tt;
     const int nT = p.nT;                                                   // 4..16, uniform over the batch
-    dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);       // both waves write identical tables
+    if (TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);   // both waves write identical tables
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
@@ -289,6 +289,8 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         double* outb = p.out + b * (int64_t)mT * mK;
         const double* Kqb = p.Kq + b * p.kq_stride;
         const int64_t b_next = seek(b + gridDim.x, n_next, koff_next);
+        if (!TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, S + 600, TT, W,
+                                                        tt, nT, S);      // per-surface maturities; scratch = the free S plane
         __syncthreads();                                   // staging and both flags visible
         const bool redo = XCH[X_BAD] != 0.0 || XCH[X_BAD + 1] != 0.0 || tt.unsorted;       // workgroup-uniform
         if (redo) {
@@ -406,7 +408,8 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
 // Dispatch for variable strike counts: class 4..64 on the one-wavefront kernel, class 65..128 on the two-wavefront
 // kernel, then the filtered generic redo pass.  Returns 1 if dispatched, 0 if the batch is not covered.
 inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name) {
-    if (p.nT < 4 || p.nT > DT || p.t_stride != 0 || p.tq_stride != 0 || p.mT > D_MAX_MT) return 0;
+    if (p.nT < 4 || p.nT > DT || p.mT > D_MAX_MT) return 0;
+    const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
     if (p.nK < 4 || p.nK > 128) return 0;
     if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
@@ -423,8 +426,10 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
     {                                                                                                                \
         const size_t lds = dense_var_lds_bytes<1>(p.mT);                                                             \
         const int64_t grid = grid_for(lds);                                                                          \
-        if (wl) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
-        else hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);     \
+        if (wl && tsh) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
+        else if (tsh) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
+        else if (wl) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);    \
+        else hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);           \
     }
 #define IVS_VAR_LAUNCH2(M, LO, HI, TAG)                                                                              \
     {                                                                                                                \
@@ -432,12 +437,16 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
         const int64_t grid = grid_for(lds);                                                                          \
         static bool attr = false;                                                                                    \
         if (!attr) {                                                                                                 \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, true>));                          \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, false>));                         \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, true, true>));                    \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, false, true>));                   \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, true, false>));                   \
+            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, false, false>));                  \
             attr = true;                                                                                             \
         }                                                                                                            \
-        if (wl) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);    \
-        else hipLaunchKernelGGL((surface_dense_var2_kernel<M, false>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);      \
+        if (wl && tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, true>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);    \
+        else if (tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, true>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);    \
+        else if (wl) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, false>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);     \
+        else hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, false>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);            \
     }
 #define IVS_VAR_CASE(M, NAME)                                                  \
     case M:                                                                    \

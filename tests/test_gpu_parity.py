@@ -261,6 +261,36 @@ def test_dense_var_runtime_maturity_counts(method, nT):
     close(out.cpu().numpy(), ref, method, f"ragged wide nT={nT} {method}")
 
 
+@pytest.mark.parametrize("method", DENSE_METHODS)
+def test_dense_var_per_surface_maturities(method):
+    """Every snapshot with its own maturities and its own query maturities (t_stride / tq_stride != 0) on the
+    variable-shape kernels: uniform 48 / 100 strikes, 16 and 9 maturities, and a ragged batch."""
+    from iv_interpolation_amd import engine, synth
+    r = np.random.default_rng(5150)
+    Kq = np.linspace(0.7, 1.3, 64)
+    for nK, nT, B in ((48, 16, 301), (100, 9, 150)):
+        d = synth.numpy_batch(B, nK, nT, seed=31 + nK)
+        Tb = d["T"][None, :] * (1.0 + 0.3 * r.random((B, 1))) + np.cumsum(r.uniform(0, 1e-3, (B, nT)), axis=1)
+        Tqb = np.sort(np.exp(r.uniform(np.log(0.5 * Tb[:, :1]), np.log(1.2 * Tb[:, -1:]), (B, 16))), axis=1)
+        Tqb[:, 5] = Tb[:, 2]; Tqb.sort(axis=1)
+        out, st = engine.surface_batch(dev(d["K"]), dev(Tb), dev(d["sigma"]), dev(Kq), dev(Tqb), method)
+        assert engine.last_kernel().startswith("surface_dense_var_kernel"), engine.last_kernel()
+        ref, rst = O.surface_batch(d["K"], Tb, d["sigma"], Kq, Tqb, METHODS[method])
+        assert np.array_equal(st.cpu().numpy(), rst)
+        close(out.cpu().numpy(), ref, method, f"per-surface T nK={nK} nT={nT} {method}")
+    d = synth.numpy_ragged_batch(200, 16, 8, 128, seed=99)
+    B = 200
+    Tb = d["T"][None, :] * (1.0 + 0.3 * r.random((B, 1)))
+    Tqb = np.sort(np.exp(r.uniform(np.log(0.5 * Tb[:, :1]), np.log(1.2 * Tb[:, -1:]), (B, 24))), axis=1)
+    Tqb[7] = Tqb[7][::-1]                                              # one surface with descending queries -> generic redo
+    out, st = engine.surface_batch(dev(d["K"]), dev(Tb), dev(d["sigma"]), dev(Kq), dev(Tqb), method,
+                                   k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=16)
+    assert engine.last_kernel().startswith("surface_dense_var_kernel")
+    ref, rst = O.surface_batch(d["K"], Tb, d["sigma"], Kq, Tqb, METHODS[method], k_off=d["k_off"])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    close(out.cpu().numpy(), ref, method, f"ragged per-surface T {method}")
+
+
 @pytest.mark.parametrize("method", ["linear", "cubic"])
 def test_dense_var_ragged_with_nan_and_tiny_surfaces(method):
     """Ragged batch mixing both size classes, surfaces with NaN quotes and surfaces below 4 strikes (generic redo)."""
