@@ -507,6 +507,11 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
         tt.pm_last = SC[288 + nT - 1];
         __syncthreads();
     }
+    if (!d_is_hermite(METHOD) && lane < DT) {          // lerp methods: {T_j, T_j+1, 1/dt, dt} per interval
+        const bool in = lane < nT - 1;
+        const double t0 = in ? Tsh[lane] : 0.0, t1 = in ? Tsh[lane + 1] : 1.0;
+        TT[lane * 4 + 0] = t0; TT[lane * 4 + 1] = t1; TT[lane * 4 + 2] = refined_rcp(t1 - t0); TT[lane * 4 + 3] = t1 - t0;
+    }
     if (d_is_local(METHOD) && lane < DT) {
         double r0, r1, r2;
         local_tables<DT>(Tsh, lane, r0, r1, r2);
@@ -663,6 +668,33 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
     } else {
 #pragma unroll
         for (int jv = 0; jv < DT - 1; ++jv) {
+            if (!WLDS) {
+#pragma clang fp contract(off)
+                // many query rows per interval (mT > 16): np.interp's slope of the interval once per lane, two
+                // operations per output row (same arithmetic as lerp_fast, hence the same bits)
+                const int n = tt.n_iv(jv);
+                if (n == 0) continue;
+                const double2 tj = *reinterpret_cast<const double2*>(TT + jv * 4);          // {T_j, T_j+1}
+                const double2 tr = *reinterpret_cast<const double2*>(TT + jv * 4 + 2);      // {1/dt, dt}
+                const double a = z[jv + 1] - z[jv];
+                const double q = a * tr.x;
+                const double rem = __builtin_fma(-q, tr.y, a);
+                const double slope = __builtin_fma(rem, tr.x, q);
+                const double aa = __builtin_fabs(a);
+                const bool slow_iv = !div_safe(tr.y) || !((a == 0.0) || (aa >= 0x1p-500 && aa <= 0x1p500));
+                for (int c = 0; c < n; ++c, ++tq) {
+                    if (!mine(tq)) continue;
+                    const double xt = readlane_f64(tt.w0, tq);
+                    const double res = slope * (xt - tj.x) + z[jv];
+                    const bool slow = slow_iv || __builtin_isnan(res);
+                    double r = (tj.x == xt) ? z[jv] : res;
+                    if (__builtin_expect(__ballot(slow) != 0ull, 0)) {
+                        if (slow) r = lerp_np(xt, tj.x, z[jv], tj.y, z[jv + 1]);
+                    }
+                    put(tq, r);
+                }
+                continue;
+            }
             for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
                 if (!mine(tq)) continue;
                 double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
