@@ -376,6 +376,48 @@ __device__ __forceinline__ void dense_maturity_slopes_local(const double (&z)[DT
     }
 }
 
+// Run-time maturity count nT (4..16): tables are all-zero beyond nT, so secants beyond the last knot come out 0 and are
+// replaced by akima's linear extension F(i) = 2 F(i-1) - F(i-2); pchip's one-sided rule moves to knot nT - 1.
+template <int METHOD>
+__device__ __forceinline__ void dense_maturity_slopes_local_rt(const double (&z)[DT], const double* TT, double (&s)[DT],
+                                                               int nT) {
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    double F[DT + 3];                               // F[i] = m_{i-2}
+#pragma unroll
+    for (int i = 0; i < DT - 1; ++i) F[i + 2] = (z[i + 1] - z[i]) * TT[i * 4];
+    F[DT + 1] = 0.0; F[DT + 2] = 0.0; F[0] = 0.0; F[1] = 0.0;
+    if (!AK) {
+        s[0] = pchip_edge(F[2], F[3], TT[1], TT[2]);
+#pragma unroll
+        for (int i = 1; i < DT; ++i) {
+            const double w1 = TT[i * 4 + 1], w2 = TT[i * 4 + 2];
+            const double v = pchip_knot(F[i + 1], F[i + 2], w1, w2);
+            const double e = pchip_edge(F[i + 1], F[i], w1, w2);
+            s[i] = (i == nT - 1) ? e : v;                 // wave-uniform select
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        F[1] = 2.0 * F[2] - F[3]; F[0] = 2.0 * F[1] - F[2];
+#pragma unroll
+        for (int i = 4; i < DT + 3; ++i) {
+            const int idx = i - 2;
+            F[i] = (idx == nT - 1 || idx == nT) ? 2.0 * F[i - 1] - F[i - 2] : F[i];
+        }
+        double fmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            const double f = akima_f12(F[i], F[i + 1], F[i + 2], F[i + 3]);
+            fmax = (i < nT) ? __builtin_fmax(fmax, f) : fmax;
+        }
+        const double thr = 1e-9 * fmax;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            s[i] = akima_knot(F[i], F[i + 1], F[i + 2], F[i + 3], thr);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Strike-direction slopes of all 16 rows of the staged surface: K-phase (k-lane factorisation) followed by
 // the segmented sweeps (rs-lane).  Reads Y and Ksh, writes RDX and (last) the S plane; the factor tables
 // live in the S plane until then.  Must be called by all 64 lanes of the workgroup.
@@ -475,6 +517,7 @@ struct TqTables {
 template <int NKB>
 __device__ __forceinline__ void factor_tables_var(const double* X, int n, int lane, double* AL, double* CP, double* PP,
                                                   double* QQ, double* PM, double* PI, double* PSI, double* RDX);
+__device__ __forceinline__ void local_tables_rt(const double* X, int n, int i, double& r0, double& r1, double& r2);
 
 // T-phase: maturity-direction factor tables (LDS, TT) + per-query-row weights (registers, lane = tq; also W in LDS
 // when WLDS) + row counts per class.  Needs mT <= 64.  All 64 lanes must call it; ends with a barrier.
@@ -514,7 +557,8 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
     }
     if (d_is_local(METHOD) && lane < DT) {
         double r0, r1, r2;
-        local_tables<DT>(Tsh, lane, r0, r1, r2);
+        if (NTR) local_tables_rt(Tsh, nT, lane, r0, r1, r2);
+        else local_tables<DT>(Tsh, lane, r0, r1, r2);
         TT[lane * 4 + 0] = r0; TT[lane * 4 + 1] = r1; TT[lane * 4 + 2] = r2; TT[lane * 4 + 3] = 0.0;
     }
     const int tq = lane;
@@ -612,7 +656,8 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         double prev = 0.0;
         const double pm_last = NTR ? readlane_f64(tt.pm_last, 0) : 0.0;      // uniform -> SGPRs
         if (d_is_local(METHOD)) {
-            dense_maturity_slopes_local<METHOD>(z, TT, s);
+            if (NTR) dense_maturity_slopes_local_rt<METHOD>(z, TT, s, nT);
+            else dense_maturity_slopes_local<METHOD>(z, TT, s);
             // pin the slopes here: otherwise they (and, transitively, the strike evaluation with its 64 gathered
             // operands) are sunk into the row loops below and the live set overflows the register file
 #pragma unroll

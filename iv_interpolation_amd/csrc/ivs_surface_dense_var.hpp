@@ -215,13 +215,126 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
     }
 }
 
+// ---- local-slope methods (pchip, akima) with a run-time knot count (scheme: dense_strike_slopes_local)
+__device__ __forceinline__ void local_tables_rt(const double* X, int n, int i, double& r0, double& r1, double& r2) {
+    const bool in = i < n;
+    const int ii = in ? i : n - 1;
+    const double x0 = X[ii];
+    const double xp = X[ii + 1 < n ? ii + 1 : n - 1], xm = X[ii > 0 ? ii - 1 : 0];
+    const double dxc = xp - x0, dxm = x0 - xm;
+    const bool first = ii == 0, last = ii == n - 1;
+    const double h0 = first ? dxc : dxm;
+    const double h1 = first ? X[2] - X[1] : X[n - 2] - X[n - 3];
+    const double rs = refined_rcp(h0 + h1);
+    r0 = (in && !last) ? refined_rcp(dxc) : 0.0;
+    r1 = (first || last) ? (2.0 * h0 + h1) * rs : 2.0 * dxc + dxm;
+    r2 = (first || last) ? h0 * rs : dxc + 2.0 * dxm;
+    if (!in) { r1 = 0.0; r2 = 0.0; }
+}
+
+// Final secant sequence F[i] = m_{kb-2+i}, i = 0..18, of one 16-knot segment of a row (yr: the row in the padded LDS
+// layout, kp = padded index of knot kb, R0 = 1/dx table, zero from interval n-1 on).  Akima: secants left of knot 0 and
+// beyond knot n-1 by linear extension of the secant sequence, F(i) = 2 F(i-1) - F(i-2).
+template <bool AK>
+__device__ __forceinline__ void segment_secants(const double* yr, const double* R0, int kb, int kp, int n, double (&F)[19]) {
+    const bool s_first = kb == 0;
+    double y[20];                                   // y[m+2] = y_{kb+m}, m = -2..17
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(yr + kp + 2 * c);
+        y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
+    }
+    y[1] = yr[s_first ? 0 : kp - 3];
+    y[18] = yr[kp + 18];
+    y[0] = yr[s_first ? 0 : kp - 4];               // pchip too: the one-sided rule at knot n-1 = kb needs m_{n-3}
+    y[19] = AK ? yr[kp + 19] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 19; ++i) {
+        const int ti = i == 0 ? kp - 4 : (i == 1 ? kp - 3 : (i == 18 ? kp + 18 : kp + i - 2));
+        F[i] = (y[i + 1] - y[i]) * R0[(s_first && i < 2) ? 0 : ti];
+    }
+    if (AK) {
+        const double l1 = 2.0 * F[2] - F[3], l0 = 2.0 * l1 - F[2];
+        F[1] = s_first ? l1 : F[1]; F[0] = s_first ? l0 : F[0];
+#pragma unroll
+        for (int i = 2; i < 19; ++i) {
+            const int idx = kb - 2 + i;
+            F[i] = (idx == n - 1 || idx == n) ? 2.0 * F[i - 1] - F[i - 2] : F[i];
+        }
+    }
+}
+// largest |second difference| over the segment's knots below n (akima's switch to the arithmetic mean)
+__device__ __forceinline__ double segment_akima_fmax(const double (&F)[19], int kb, int n) {
+    double fmax = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const double f = akima_f12(F[m], F[m + 1], F[m + 2], F[m + 3]);
+        fmax = (kb + m < n) ? __builtin_fmax(fmax, f) : fmax;
+    }
+    return fmax;
+}
+template <int METHOD>
+__device__ __forceinline__ void segment_slopes(const double (&F)[19], const double* R1, const double* R2, int kb, int kp,
+                                               int n, double thr, double (&d)[16]) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if (METHOD == IVS_AKIMA) d[m] = akima_knot(F[m], F[m + 1], F[m + 2], F[m + 3], thr);
+        else {
+            const double w1 = R1[kp + m], w2 = R2[kp + m];
+            double v = pchip_knot(F[m + 1], F[m + 2], w1, w2);
+            if (m == 0) { const double e = pchip_edge(F[2], F[3], w1, w2); v = kb == 0 ? e : v; }
+            const double e = pchip_edge(F[m + 1], F[m], w1, w2);        // one-sided rule at the last knot
+            v = (kb + m == n - 1) ? e : v;
+            d[m] = v;
+        }
+        if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Strike-direction slopes, local methods, n <= 64 (one wavefront per surface).  Tables alias the S plane.
+template <int METHOD>
+__device__ __forceinline__ void dense_strike_slopes_local_var(const double* Y, double* S, const double* Ksh, double* RDX,
+                                                              int n, int lane) {
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    constexpr int RS = 72;
+    double* R0 = S;
+    double* R1 = S + 80;
+    double* R2 = S + 160;
+    {
+        double r0, r1, r2;
+        local_tables_rt(Ksh, n, lane, r0, r1, r2);
+        const int kl = d_sl(lane);
+        R0[kl] = r0; R1[kl] = r1; R2[kl] = r2; RDX[lane] = r0;
+    }
+    __syncthreads();
+    const int rs_t = lane >> 2, rs_seg = lane & 3;
+    const int kb = 16 * rs_seg, kp = 18 * rs_seg;
+    double F[19], d[16];
+    segment_secants<AK>(Y + rs_t * RS, R0, kb, kp, n, F);
+    double thr = 0.0;
+    if (AK) {
+        double fmax = segment_akima_fmax(F, kb, n);
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));      // the row's 4 segments = one quad
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
+        thr = 1e-9 * fmax;
+    }
+    segment_slopes<METHOD>(F, R1, R2, kb, kp, n, thr, d);
+    __syncthreads();                               // table reads done: the S plane may be overwritten
+    double* srow = S + rs_t * RS + kp;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
+        *reinterpret_cast<double2*>(srow + 2 * c) = v;
+    }
+}
+
 struct VarRange { int lo, hi; };   // strike counts served by a launch
 
 // TSHARED: T and Tq shared by the batch (T-phase once per workgroup); otherwise per surface (t_stride / tq_stride),
 // the T-phase then runs inside the loop with its scratch in the S plane, which is free until the slopes are written.
 template <int METHOD, int NKB, bool WLDS, bool TSHARED = true>
 __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
-    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool CUB = d_is_hermite(METHOD);
     constexpr int RS = NKB * 72;
     constexpr int KCAP = NKB * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -312,8 +425,11 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
             tag(b);
         } else {
             __syncthreads();
-            if (CUB) {
+            if (d_is_nak(METHOD)) {
                 dense_strike_slopes_var<NKB>(Y, S, Ksh, RDX, n, lane);
+                __syncthreads();
+            } else if (d_is_local(METHOD)) {
+                dense_strike_slopes_local_var<METHOD>(Y, S, Ksh, RDX, n, lane);
                 __syncthreads();
             }
             if (!kq_shared) load_xq(Kqb);
@@ -339,7 +455,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
                 const int o0 = d_sl(jj), o1 = d_sl(jj + 1);
                 double z[DT];
                 if (CUB) {
-                    const bool ok = !left && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
+                    const bool ok = !left && ((xq <= xl) || d_extrap_right(METHOD));
                     const double u = xq - x0, t = u * RDX[jj], omt = 1.0 - t;
                     const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
                     const double w1 = t * t * (3.0 - 2.0 * t);
@@ -388,6 +504,10 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
                             for (int r = 0; r < DT; ++r) z[r] = lerp_np(xq, x0, Y[r * RS + o0], x1, Y[r * RS + o1]);
                         }
                     }
+                }
+                if (d_is_local(METHOD)) {
+#pragma unroll
+                    for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
                 }
                 if (act) dense_maturity_pass<METHOD, WLDS, false, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
             }

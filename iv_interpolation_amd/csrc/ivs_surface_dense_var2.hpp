@@ -217,9 +217,53 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
     }
 }
 
+// Local methods (pchip, akima), 65..128 strikes: wave w owns the logical segments 4w .. 4w+3.  No carries cross the
+// waves (neighbouring quotes are read from LDS); akima's row maximum is taken over all 8 segments by letting every lane
+// also scan the partner segment of the other wave.
+template <int METHOD>
+__device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, double* S, const double* Ksh, int n, int lane,
+                                                               int w) {
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    double* R0 = S;
+    double* R1 = S + 152;
+    double* R2 = S + 304;
+    {
+        double r0, r1, r2;
+        local_tables_rt(Ksh, n, w * 64 + lane, r0, r1, r2);
+        const int kl = d_sl(w * 64 + lane);
+        R0[kl] = r0; R1[kl] = r1; R2[kl] = r2;
+    }
+    __syncthreads();
+    const int rs_t = lane >> 2, rs_seg = lane & 3;
+    const int sg = rs_seg + 4 * w, kb = 16 * sg, kp = 18 * sg;
+    const double* yr = Y + v2_row(rs_t);
+    double F[19], d[16];
+    double thr = 0.0;
+    if (AK) {
+        const int sgp = rs_seg + 4 * (1 - w);
+        segment_secants<true>(yr, R0, 16 * sgp, 18 * sgp, n, F);
+        double fmax = segment_akima_fmax(F, 16 * sgp, n);
+        segment_secants<true>(yr, R0, kb, kp, n, F);
+        fmax = __builtin_fmax(fmax, segment_akima_fmax(F, kb, n));
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
+        thr = 1e-9 * fmax;
+    } else {
+        segment_secants<false>(yr, R0, kb, kp, n, F);
+    }
+    segment_slopes<METHOD>(F, R1, R2, kb, kp, n, thr, d);
+    __syncthreads();                               // table reads done: the S plane may be overwritten
+    double* srow = S + v2_row(rs_t) + kp;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
+        *reinterpret_cast<double2*>(srow + 2 * c) = v;
+    }
+}
+
 template <int METHOD, bool WLDS, bool TSHARED = true>
 __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
-    constexpr bool CUB = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool CUB = d_is_hermite(METHOD);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave index, scalar
@@ -296,8 +340,11 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         if (redo) {
             tag(b);
         } else {
-            if (CUB) {
+            if (d_is_nak(METHOD)) {
                 dense_strike_slopes_var2(Y, S, Ksh, XCH, n, lane, w);
+                __syncthreads();
+            } else if (d_is_local(METHOD)) {
+                dense_strike_slopes_local_var2<METHOD>(Y, S, Ksh, n, lane, w);
                 __syncthreads();
             }
             if (!kq_shared) load_xq(Kqb);
@@ -331,7 +378,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                     const double* Yb = Y;
                     const double* Sb = S;
                     if (CUB) {
-                        const bool ok = !left && ((xq <= xl) || METHOD == IVS_CUBICSPLINE);
+                        const bool ok = !left && ((xq <= xl) || d_extrap_right(METHOD));
                         const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;   // no 1/dx table: LDS budget
                         const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
                         const double w1 = t * t * (3.0 - 2.0 * t);
@@ -391,11 +438,19 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                     __syncthreads();
 #pragma unroll
                     for (int r = 0; r < DT; ++r) z[r] = ZX[r * 64 + lane];
+                    if (d_is_local(METHOD)) {
+#pragma unroll
+                        for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
+                    }
                     const int half = (mT + 1) >> 1;
                     if (act) dense_maturity_pass<METHOD, WLDS, true, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp,
                                                                            w == 0 ? 0 : half, w == 0 ? half : mT, nT);
                 } else {
                     strike_rows(std::integral_constant<int, DT>{}, 0);
+                    if (d_is_local(METHOD)) {
+#pragma unroll
+                        for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));
+                    }
                     if (act) dense_maturity_pass<METHOD, WLDS, false, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
                 }
             }
@@ -459,6 +514,8 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
         IVS_VAR_CASE(IVS_CUBIC, "surface_dense_var_kernel<cubic>")
         IVS_VAR_CASE(IVS_CUBICSPLINE, "surface_dense_var_kernel<cubicspline>")
         IVS_VAR_CASE(IVS_SLINEAR, "surface_dense_var_kernel<slinear>")
+        IVS_VAR_CASE(IVS_PCHIP, "surface_dense_var_kernel<pchip>")
+        IVS_VAR_CASE(IVS_AKIMA, "surface_dense_var_kernel<akima>")
         default: return 0;
     }
 #undef IVS_VAR_CASE

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
            "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES}
-DENSE_METHODS = ["linear", "cubic", "cubicspline", "slinear"]          # methods with dense AND variable-shape fast kernels
-DENSE64_METHODS = DENSE_METHODS + ["pchip", "akima"]                   # methods with a 64x16 dense kernel
+DENSE_METHODS = ["linear", "cubic", "cubicspline", "slinear", "pchip", "akima"]     # methods with dense and variable-shape kernels
+DENSE64_METHODS = DENSE_METHODS
 EXACT = ("linear", "nearest", "zero", "from_derivatives")               # bit-exact against the oracle / pandas
 RTOL, ATOL = 1e-11, 1e-12
 CASES = SymbolCases()
