@@ -69,6 +69,12 @@ def load():
         raise EngineUnavailable(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch-ROCm ships its own libamdhip64; libivs.so must bind to THAT copy, so torch has to be loaded first.  Loading
+    # libivs.so (-> /opt/rocm's runtime) before torch leaves two HIP runtimes in the process and torch sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -236,7 +236,9 @@ class IVInterpolator:
                     raw_idx = np.full(total_q, -1, np.int64)
                     raw_idx[gpos] = np.arange(len(gpos))
                 cols[name] = _gather(v, raw_idx, int_dtype, nothing_missing)
-        sym_na = pd.isna(cols["symbol"])
+        # the forward-fill index only ever points at VALID source cells, so "symbol is null" == "no source row yet"
+        # (an integer compare instead of pd.isna over millions of Python strings)
+        sym_na = (fidx[fill_cols.index("symbol")] < 0) if "symbol" in fill_cols else pd.isna(cols["symbol"])
         keep = ~sym_na & sym_ok[sym_of_row]
         for c in REQUIRED[1:]:
             keep &= ~pd.isna(cols[c])
