@@ -1,15 +1,18 @@
-// Dense fast path for VARIABLE strike counts: 4 <= nK <= 128 per surface (uniform batches with nK != 64 and
-// ragged CSR batches, BASELINE config 5), 4..16 maturities (run time, uniform over the batch), shared T/Tq, no missing
-// quotes.
+// Dense fast path for VARIABLE strike counts: 4 <= nK <= 64 per surface on one wavefront (uniform batches with
+// nK != 64 and ragged CSR batches, BASELINE config 5), 4..16 maturities (run time, uniform over the batch), T/Tq shared
+// or per surface, no missing quotes.  Surfaces with 65..128 strikes use the two-wavefront kernel of
+// ivs_surface_dense_var2.hpp, which reuses the pieces below.
 //
 // Same three-layout scheme as ivs_surface_dense.hpp, with the strike count n a run-time value:
-//   * NKB = 1 handles surfaces with n <= 64, NKB = 2 those with 65..128 (two 64-strike blocks per k-lane, two
-//     16-strike segments per rs-lane); a ragged batch is served by one launch per class, each launch skipping the
-//     surfaces of the other class (wave-uniform test on k_off);
 //   * knots beyond n are neutral elements: +inf in the strike array (searches stop), identity matrices in the
 //     pivot scan, 1.0 in the segment products, masked steps in the sweeps;
 //   * the last row of the not-a-knot system sits at a run-time position, so the sweeps use a three-tap right-hand
-//     side  r_i = PM_i*dy_{i-2} + PP_i*dy_{i-1} + QQ_i*dy_i  (PM is zero except on the last row).
+//     side  r_i = PM_i*dy_{i-2} + PP_i*dy_{i-1} + QQ_i*dy_i  (PM is zero except on the last row);
+//   * pchip / akima: per-segment secant sequences with run-time fix-ups (segment_secants / segment_slopes);
+//   * a ragged batch is served by one launch per size class, each launch skipping the surfaces of the other class
+//     (wave-uniform test on k_off).
+// The templates keep an NKB parameter (strike blocks of 64 per k-lane): NKB = 2 was the one-wavefront kernel for
+// 65..128 strikes (71 M surfaces/s), superseded by the two-wavefront kernel (98 M) and no longer instantiated.
 // Surfaces outside [4,128], with a NaN quote, or batches with unsorted Tq are tagged for the generic redo pass.
 #pragma once
 #include "ivs_surface_dense.hpp"
