@@ -331,12 +331,42 @@ __device__ __forceinline__ void dense_strike_slopes_local_var(const double* Y, d
     }
 }
 
-struct VarRange { int lo, hi; };   // strike counts served by a launch
+// Work list of a launch.  Ragged batches are classified once per call (var_classify_kernel) into one list per size
+// class, so that no kernel walks over -- and reads the offsets of -- the other class's surfaces (that cost 9-18 % of
+// the launch on config 5).  items == nullptr: the launch serves surfaces 0..B-1 of a uniform batch.
+struct VarItem { int32_t b; int32_t n; int64_t koff; };
+struct VarList { const VarItem* items; const int32_t* count; };
+
+__global__ __launch_bounds__(256) void var_classify_kernel(SurfaceParams p, VarItem* l1, VarItem* l2, int32_t* counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); b0 < p.B; b0 += stride) {     // wave-uniform trip count
+        const int64_t b = b0 + lane;
+        const bool in = b < p.B;
+        const int64_t ko = in ? p.k_off[b] : 0;
+        const int64_t nn = in ? p.k_off[b + 1] - ko : 0;
+        const bool c1 = in && nn >= 4 && nn <= 64, c2 = in && nn >= 65 && nn <= 128;
+        if (in && !c1 && !c2)                                   // not served by a dense kernel: generic redo pass
+            reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)p.mT * p.mK)[0] = D_SENTINEL;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls) {
+            const bool c = cls == 0 ? c1 : c2;
+            const unsigned long long m = __ballot(c);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counts[cls], __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (c) (cls == 0 ? l1 : l2)[base + __popcll(m & lt)] = VarItem{(int32_t)b, (int32_t)nn, ko};
+        }
+    }
+}
+
 
 // TSHARED: T and Tq shared by the batch (T-phase once per workgroup); otherwise per surface (t_stride / tq_stride),
 // the T-phase then runs inside the loop with its scratch in the S plane, which is free until the slopes are written.
 template <int METHOD, int NKB, bool WLDS, bool TSHARED = true>
-__global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
+__global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams p, VarList list) {
     constexpr bool CUB = d_is_hermite(METHOD);
     constexpr int RS = NKB * 72;
     constexpr int KCAP = NKB * 64;
@@ -365,21 +395,14 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
     };
     if (kq_shared) load_xq(p.Kq);
 
-    // strike count / offset of surface b; walk to the next surface of this launch's class
-    auto count_of = [&](int64_t b, int64_t& koff) -> int {
-        if (p.k_off) { koff = p.k_off[b]; return (int)(p.k_off[b + 1] - koff); }
-        koff = b * p.k_stride; return p.nK;
+    // surface at position `it` of this launch's work list (uniform batches: position = surface number)
+    const int64_t limit = list.items ? (int64_t)*list.count : p.B;
+    auto at = [&](int64_t it, int& n, int64_t& koff) -> int64_t {
+        if (list.items) { const VarItem v = list.items[it]; n = v.n; koff = v.koff; return v.b; }
+        n = p.nK; koff = it * p.k_stride; return it;
     };
     auto tag = [&](int64_t b) {
         if (lane == 0) reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL;
-    };
-    auto seek = [&](int64_t b, int& n, int64_t& koff) -> int64_t {
-        for (; b < p.B; b += gridDim.x) {
-            n = count_of(b, koff);
-            if (n >= range.lo && n <= range.hi) break;
-            if (tag_out_of_range && (n < 4 || n > 128)) tag(b);
-        }
-        return b;
     };
 
     double pre[DT * NKB], pre_k[NKB];
@@ -402,10 +425,10 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         for (int blk = 0; blk < NKB; ++blk) { const int k = blk * 64 + lane; pre_k[blk] = k < nn ? Kb[k] : inf; }
     };
 
-    int64_t b = seek(blockIdx.x, n, koff);
-    if (b < p.B) issue_loads(b, koff, n);
+    int64_t it = blockIdx.x, b = 0;
+    if (it < limit) { b = at(it, n, koff); issue_loads(b, koff, n); }
 
-    while (b < p.B) {
+    while (it < limit) {
         __syncthreads();
         unsigned long long bad = 0ull;                     // wave-level NaN mask in scalar registers
 #pragma unroll
@@ -420,7 +443,9 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
         double* outb = p.out + b * (int64_t)mT * mK;
         const double* Kqb = p.Kq + b * p.kq_stride;
-        const int64_t b_next = seek(b + gridDim.x, n_next, koff_next);
+        const int64_t it_next = it + gridDim.x;
+        int64_t b_next = 0;
+        if (it_next < limit) b_next = at(it_next, n_next, koff_next);
         if (!TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, S + 600, TT, W,
                                                         tt, nT, S);
         const bool redo = bad != 0ull || tt.unsorted;
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
             }
             if (!kq_shared) load_xq(Kqb);
         }
-        if (b_next < p.B) issue_loads(b_next, koff_next, n_next);   // next surface flies during evaluation + maturity pass
+        if (it_next < limit) issue_loads(b_next, koff_next, n_next);   // next surface flies during evaluation + maturity pass
         if (!redo) {
 #pragma unroll 1
             for (int q0 = 0, qb = 0; q0 < mK; q0 += 64, ++qb) {
@@ -516,7 +541,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
             }
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         }
-        b = b_next; n = n_next; koff = koff_next;
+        it = it_next; b = b_next; n = n_next; koff = koff_next;
     }
 }
 

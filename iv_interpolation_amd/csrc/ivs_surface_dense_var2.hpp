@@ -262,7 +262,7 @@ __device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, 
 }
 
 template <int METHOD, bool WLDS, bool TSHARED = true>
-__global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParams p, VarRange range, int tag_out_of_range) {
+__global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParams p, VarList list) {
     constexpr bool CUB = d_is_hermite(METHOD);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -290,20 +290,13 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
     };
     if (kq_shared) load_xq(p.Kq);
 
-    auto count_of = [&](int64_t b, int64_t& koff) -> int {
-        if (p.k_off) { koff = p.k_off[b]; return (int)(p.k_off[b + 1] - koff); }
-        koff = b * p.k_stride; return p.nK;
+    const int64_t limit = list.items ? (int64_t)*list.count : p.B;
+    auto at = [&](int64_t it, int& n, int64_t& koff) -> int64_t {
+        if (list.items) { const VarItem v = list.items[it]; n = v.n; koff = v.koff; return v.b; }
+        n = p.nK; koff = it * p.k_stride; return it;
     };
     auto tag = [&](int64_t b) {
         if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL;
-    };
-    auto seek = [&](int64_t b, int& n, int64_t& koff) -> int64_t {
-        for (; b < p.B; b += gridDim.x) {
-            n = count_of(b, koff);
-            if (n >= range.lo && n <= range.hi) break;
-            if (tag_out_of_range && (n < 4 || n > 128)) tag(b);
-        }
-        return b;
     };
 
     double pre[DT], pre_k;
@@ -317,10 +310,10 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         pre_k = k < nn ? p.K[ko + k] : inf;
     };
 
-    int64_t b = seek(blockIdx.x, n, koff);
-    if (b < p.B) issue_loads(b, koff, n);
+    int64_t it = blockIdx.x, b = 0;
+    if (it < limit) { b = at(it, n, koff); issue_loads(b, koff, n); }
 
-    while (b < p.B) {
+    while (it < limit) {
         __syncthreads();                                   // previous surface fully consumed by both waves
         unsigned long long bad = 0ull;
 #pragma unroll
@@ -332,7 +325,9 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         if (lane == 0) XCH[X_BAD + w] = bad != 0ull ? 1.0 : 0.0;
         double* outb = p.out + b * (int64_t)mT * mK;
         const double* Kqb = p.Kq + b * p.kq_stride;
-        const int64_t b_next = seek(b + gridDim.x, n_next, koff_next);
+        const int64_t it_next = it + gridDim.x;
+        int64_t b_next = 0;
+        if (it_next < limit) b_next = at(it_next, n_next, koff_next);
         if (!TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, S + 600, TT, W,
                                                         tt, nT, S);      // per-surface maturities; scratch = the free S plane
         __syncthreads();                                   // staging and both flags visible
@@ -349,7 +344,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
             }
             if (!kq_shared) load_xq(Kqb);
         }
-        if (b_next < p.B) issue_loads(b_next, koff_next, n_next);
+        if (it_next < limit) issue_loads(b_next, koff_next, n_next);
         if (!redo) {
             const bool split_rows = mK <= 64;              // uniform: one query block -> the waves share it by rows
 #pragma unroll 1
@@ -456,7 +451,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
             }
             if (p.status && threadIdx.x == 0) p.status[b] = IVS_ST_OK;
         }
-        b = b_next; n = n_next; koff = koff_next;
+        it = it_next; b = b_next; n = n_next; koff = koff_next;
     }
 }
 
@@ -468,25 +463,43 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
     if (p.nK < 4 || p.nK > 128) return 0;
     if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
+    if (!(d_is_hermite(p.method) || p.method == IVS_LINEAR || p.method == IVS_SLINEAR)) return 0;
     const bool wl = p.mT <= D_WLDS_MAX_MT;
     const bool need1 = p.k_off ? true : p.nK <= 64;
     const bool need2 = p.nK > 64;
+    // ragged batch: classify once into two work lists (stream-ordered scratch: 2 x B items + 2 counters)
+    VarItem* lists = nullptr;
+    int32_t* counts = nullptr;
+    if (p.k_off) {
+        if (p.B > 0x7fffffffLL) return 0;
+        void* buf = nullptr;
+        const size_t bytes = (size_t)2 * p.B * sizeof(VarItem) + 64;
+        if (hipMallocAsync(&buf, bytes, st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        lists = reinterpret_cast<VarItem*>(buf);
+        counts = reinterpret_cast<int32_t*>(lists + 2 * p.B);
+        if (hipMemsetAsync(counts, 0, 8, st) != hipSuccess) { (void)hipFreeAsync(buf, st); return -1; }
+        int64_t cb = (p.B + 255) / 256;
+        const int64_t cap = (int64_t)num_cu * 8;
+        if (cb > cap) cb = cap;
+        hipLaunchKernelGGL(var_classify_kernel, dim3((unsigned)cb), dim3(256), 0, st, p, lists, lists + p.B, counts);
+    }
+    const VarList wl1{lists, counts}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr};
     auto grid_for = [&](size_t lds) {
         int per_cu = (int)((160 * 1024) / lds);
         per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
         int64_t g = (int64_t)num_cu * per_cu;
         return g > p.B ? p.B : g;
     };
-#define IVS_VAR_LAUNCH1(M, LO, HI, TAG)                                                                              \
+#define IVS_VAR_LAUNCH1(M)                                                                                           \
     {                                                                                                                \
         const size_t lds = dense_var_lds_bytes<1>(p.mT);                                                             \
         const int64_t grid = grid_for(lds);                                                                          \
-        if (wl && tsh) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
-        else if (tsh) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false, true>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);   \
-        else if (wl) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);    \
-        else hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, VarRange{LO, HI}, TAG);           \
+        if (wl && tsh) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);    \
+        else if (tsh) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);    \
+        else if (wl) hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);     \
+        else hipLaunchKernelGGL((surface_dense_var_kernel<M, 1, false, false>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);            \
     }
-#define IVS_VAR_LAUNCH2(M, LO, HI, TAG)                                                                              \
+#define IVS_VAR_LAUNCH2(M)                                                                                           \
     {                                                                                                                \
         const size_t lds = dense_var2_lds_bytes(p.mT);                                                               \
         const int64_t grid = grid_for(lds);                                                                          \
@@ -498,17 +511,18 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
             set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, false, false>));                  \
             attr = true;                                                                                             \
         }                                                                                                            \
-        if (wl && tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, true>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);    \
-        else if (tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, true>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);    \
-        else if (wl) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, false>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);     \
-        else hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, false>), dim3((unsigned)grid), dim3(128), lds, st, p, VarRange{LO, HI}, TAG);            \
+        if (wl && tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, true>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);     \
+        else if (tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, true>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);     \
+        else if (wl) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, false>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);      \
+        else hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, false>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);             \
     }
 #define IVS_VAR_CASE(M, NAME)                                                  \
     case M:                                                                    \
-        if (need1) IVS_VAR_LAUNCH1(M, 4, 64, 1)                                \
-        if (need2) IVS_VAR_LAUNCH2(M, 65, 128, need1 ? 0 : 1)                  \
+        if (need1) IVS_VAR_LAUNCH1(M)                                          \
+        if (need2) IVS_VAR_LAUNCH2(M)                                          \
         *name = NAME;                                                          \
         break;
+    bool known = true;
     switch (p.method) {
         IVS_VAR_CASE(IVS_LINEAR, "surface_dense_var_kernel<linear>")
         IVS_VAR_CASE(IVS_CUBIC, "surface_dense_var_kernel<cubic>")
@@ -516,14 +530,16 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
         IVS_VAR_CASE(IVS_SLINEAR, "surface_dense_var_kernel<slinear>")
         IVS_VAR_CASE(IVS_PCHIP, "surface_dense_var_kernel<pchip>")
         IVS_VAR_CASE(IVS_AKIMA, "surface_dense_var_kernel<akima>")
-        default: return 0;
+        default: known = false;
     }
 #undef IVS_VAR_CASE
 #undef IVS_VAR_LAUNCH1
 #undef IVS_VAR_LAUNCH2
-    if (hipGetLastError() != hipSuccess) return -1;
-    launch_surface_generic<true>(p, num_cu, st);
-    return 1;
+    const bool launched = known && hipGetLastError() == hipSuccess;
+    if (launched) launch_surface_generic<true>(p, num_cu, st);
+    if (lists) (void)hipFreeAsync(lists, st);                 // stream-ordered: released after the kernels above
+    if (!known) return 0;
+    return launched ? 1 : -1;
 }
 
 }  // namespace ivs
