@@ -478,7 +478,7 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
         lists = reinterpret_cast<VarItem*>(buf);
         counts = reinterpret_cast<int32_t*>(lists + 2 * p.B);
         if (hipMemsetAsync(counts, 0, 8, st) != hipSuccess) { (void)hipFreeAsync(buf, st); return -1; }
-        int64_t cb = (p.B + 255) / 256;
+        int64_t cb = (p.B + 1023) / 1024;
         const int64_t cap = (int64_t)num_cu * 8;
         if (cb > cap) cb = cap;
         hipLaunchKernelGGL(var_classify_kernel, dim3((unsigned)cb), dim3(256), 0, st, p, lists, lists + p.B, counts);
