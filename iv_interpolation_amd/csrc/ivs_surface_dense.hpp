@@ -16,6 +16,8 @@
 // Surfaces that contain a NaN quote (or batches whose Tq is not ascending) are tagged with a
 // sentinel in out[b][0] and redone by the generic kernel in a second, filtered launch.
 #pragma once
+#include <cstdlib>
+
 #include "ivs_surface_generic.hpp"
 
 namespace ivs {
@@ -820,10 +822,19 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
     };
     const bool kq_shared = p.kq_stride == 0;
     if (kq_shared) load_xq(p.Kq);
-    int64_t b = blockIdx.x;
-    if (b < p.B) prefetch(b);
+    // Surface -> workgroup mapping: the workgroups form R groups (wg % R), group r sweeps the r-th region of the batch
+    // with its G/R workgroups interleaved.  With R = 1 all 2048 resident workgroups advance through ONE window of the
+    // batch; several distant windows at once stream 4-5 % faster (tools/map_probe.hip: 5.60 -> 5.90 TB/s for this
+    // kernel's access pattern, the same effect that separates a persistent grid-stride copy from a wide-grid one).
+    const int R = p.map_groups;
+    const int64_t region = (p.B + R - 1) / R;
+    const int64_t base = (int64_t)(blockIdx.x % R) * region;
+    const int64_t b_end = base + region < p.B ? base + region : p.B;          // this group's surfaces: [base, b_end)
+    const int64_t b_step = gridDim.x / R;
+    int64_t b = base + blockIdx.x / R;
+    if (b < b_end) prefetch(b);
 
-    for (; b < p.B; b += gridDim.x) {
+    for (; b < b_end; b += b_step) {
         __syncthreads();                                   // everyone is done reading the previous surface's LDS
         stamp(-1);
         // ---- stage quotes: chunk i, lane -> row t = 2i + (lane>>5), k = 2*(lane&31)
@@ -839,7 +850,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         if (!t_shared) t_phase(p.T + b * p.t_stride, p.Tq + b * p.tq_stride);   // contains a barrier
         if (bad != 0ull || tt.unsorted) {                  // wave-uniform: leave it to the generic kernel
             if (lane == 0) reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;
-            prefetch(b + gridDim.x < p.B ? b + gridDim.x : p.B - 1);
+            prefetch(b + b_step < b_end ? b + b_step : b);
             continue;
         }
         __syncthreads();
@@ -848,8 +859,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         if (!kq_shared) load_xq(Kqb);
         {   // next surface's loads fly during the whole computation; past the end the last surface is re-read
             // (harmless) so that the prefetch registers are written on every path
-            const int64_t bn = b + gridDim.x;
-            prefetch(bn < p.B ? bn : p.B - 1);
+            const int64_t bn = b + b_step;
+            prefetch(bn < b_end ? bn : b);
         }
         if (d_is_nak(METHOD)) {
             dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
@@ -973,8 +984,19 @@ inline bool launch_surface_generic(const SurfaceParams& p, int num_cu, hipStream
 
 // Dense dispatch.  Returns 1 if dispatched (dense kernel + filtered generic redo pass), 0 if the
 // shape is not covered by a dense kernel.
-inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name,
+// number of workgroup groups for a grid / batch (see the mapping comment in surface_dense_kernel); IVS_MAP_GROUPS
+// overrides it for experiments
+inline int dense_map_groups(int64_t grid, int64_t B) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("IVS_MAP_GROUPS"); forced = e ? atoi(e) : 0; }
+    int r = forced > 0 ? forced : 8;
+    while (r > 1 && (grid % r != 0 || B < (int64_t)64 * grid)) r >>= 1;      // small batches: one window
+    return r < 1 ? 1 : r;
+}
+
+inline int launch_surface_dense(const SurfaceParams& p_in, int num_cu, hipStream_t st, const char** name,
                                 unsigned long long* dbg = nullptr, int64_t* grid_out = nullptr) {
+    SurfaceParams p = p_in;
     if (p.k_off || p.nK != DK || p.nT != DT) return 0;
     if (p.k_stride != 0 && p.k_stride < DK) return 0;
     if (reinterpret_cast<uintptr_t>(p.sigma) & 15) return 0;
@@ -986,6 +1008,7 @@ inline int launch_surface_dense(const SurfaceParams& p, int num_cu, hipStream_t 
     int64_t grid = (int64_t)num_cu * per_cu;
     if (grid > p.B) grid = p.B;
     if (grid_out) *grid_out = grid;
+    p.map_groups = dense_map_groups(grid, p.B);
     const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
     const bool wl = p.mT <= D_WLDS_MAX_MT;
     if (dbg) {   // diagnostic build: cubic and linear, shared T only

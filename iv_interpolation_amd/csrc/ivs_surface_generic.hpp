@@ -20,6 +20,7 @@ struct SurfaceParams {
     const double* Kq; int64_t kq_stride; int mK;
     const double* Tq; int64_t tq_stride; int mT;
     double* out; int32_t* status; int method;
+    int map_groups;      // dense kernels: workgroups are split into this many groups, group r sweeps region r of the batch
 };
 
 constexpr int GEN_NTMAX = 32;

@@ -7,7 +7,7 @@ import torch
 from iv_interpolation_amd import _lib, synth
 
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--method", default="cubic")
-ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--batch", type=int, default=1_000_000)
+ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--groups", default="", help="comma list: IVS_MAP_GROUPS seen by each lib at its first call"); ap.add_argument("--batch", type=int, default=1_000_000)
 ap.add_argument("--nk", type=int, default=64); ap.add_argument("--mk", type=int, default=64); ap.add_argument("--mt", type=int, default=16)
 a = ap.parse_args()
 libs = []
@@ -26,7 +26,10 @@ def run(lib):
                                    torch.cuda.current_stream().cuda_stream)
     assert rc == 0
 times = [[] for _ in libs]
-for lib in libs:
+groups = a.groups.split(",") if a.groups else []
+for i, lib in enumerate(libs):
+    if groups:
+        os.environ["IVS_MAP_GROUPS"] = groups[i]      # read once per library instance, at its first call
     run(lib); run(lib)
 torch.cuda.synchronize()
 for r in range(a.rounds):
