@@ -288,7 +288,7 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
 
     if (!ivs::launch_surface_generic<false>(p, num_cu(), st))
         return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d x nT=%d needs %zu B of LDS (> 160 KiB)", nK, nT,
-                    ivs::generic_lds_bytes(nK, nT));
+                    ivs::generic_lds_bytes(nK, nT, ivs::method_is_cubic(method)));
     g_last_kernel = "surface_generic_kernel";
     return check_launch("surface_generic_kernel");
 }

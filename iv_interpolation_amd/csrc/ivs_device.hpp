@@ -162,7 +162,7 @@ struct CView {
 };
 
 // methods that evaluate a C1 piecewise cubic from knot slopes (not-a-knot solve, pchip or akima local rules)
-__device__ __forceinline__ bool method_is_cubic(int m) {
+__host__ __device__ __forceinline__ bool method_is_cubic(int m) {
     return m == IVS_CUBIC || m == IVS_CUBICSPLINE || m == IVS_PCHIP || m == IVS_AKIMA;
 }
 __device__ __forceinline__ bool method_extrapolates_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }

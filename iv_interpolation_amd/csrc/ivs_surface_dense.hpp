@@ -969,7 +969,8 @@ inline void set_max_lds(const void* fn) {
 // shape does not fit in LDS.
 template <bool FILTER>
 inline bool launch_surface_generic(const SurfaceParams& p, int num_cu, hipStream_t st) {
-    const size_t lds = generic_lds_bytes(p.nK, p.nT);
+    if (p.nK > 65535) return false;                               // 16-bit strike indices
+    const size_t lds = generic_lds_bytes(p.nK, p.nT, method_is_cubic(p.method));
     if (lds > 160 * 1024) return false;
     static bool attr = false;
     if (!attr) { set_max_lds(reinterpret_cast<const void*>(surface_generic_kernel<FILTER>)); attr = true; }

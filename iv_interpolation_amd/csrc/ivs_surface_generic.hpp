@@ -2,7 +2,7 @@
 //
 // One 64-lane workgroup (= one wavefront) per surface, grid-stride over the batch.
 //   1. quotes of row t are loaded coalesced (lane = strike) and compacted with a wave ballot
-//      into LDS (xs/ys[t][rank]); rows keep their own knot sets (NaN = missing quote).
+//      into LDS (strike index and value [t][rank]); rows keep their own knot sets (NaN = missing quote).
 //   2. cubic methods: lane t runs the not-a-knot Thomas recurrence of row t in LDS.
 //   3. per block of 64 query strikes (lane = query): evaluate every row at the lane's strike,
 //      compacting non-NaN results into a lane-private LDS column; solve the column's own
@@ -25,18 +25,26 @@ struct SurfaceParams {
 
 constexpr int GEN_NTMAX = 32;
 
-// LDS carve (per workgroup) in doubles; LK = nKmax + 1 (row pad)
-__host__ __device__ inline size_t generic_lds_bytes(int nKmax, int nT) {
+// LDS carve (per workgroup); LK = nKmax + 1 (row pad).  `slopes`: the method needs knot slopes (cubic, cubicspline,
+// pchip, akima); the others (linear, slinear, nearest, zero, from_derivatives) carry neither slope planes nor
+// Thomas scratch, which takes 64x16 surfaces from 51 KB (3 workgroups per CU) to 19 KB (8 per CU).
+// Without slopes the compacted strikes are kept as 16-bit indices into Ksh; the cubic methods keep a copy of the
+// values (their serial Thomas recurrence would pay the index indirection on every step: measured -8 %).
+__host__ __device__ inline size_t generic_lds_bytes(int nKmax, int nT, bool slopes = true) {
     size_t LK = (size_t)nKmax + 1;
     size_t rows = (size_t)nT * LK;
     size_t scratch = rows > (size_t)nT * 64 ? rows : (size_t)nT * 64;   // row cp[] aliases column cp[]
     size_t doubles = (size_t)nKmax + GEN_NTMAX      // Ksh, Tsh
-                     + 3 * rows                      // xs, ys, ss
-                     + scratch                       // cps / ccp
-                     + 2 * (size_t)nT * 64;          // cz, cs
-    return doubles * 8 + (size_t)nT * 64 /*ctidx*/ + GEN_NTMAX * 4 /*nrow*/;
+                     + rows                          // ys
+                     + (size_t)nT * 64;              // cz
+    if (slopes) doubles += 2 * rows + scratch + (size_t)nT * 64;       // xs, ss, cps / ccp, cs
+    return doubles * 8 + (slopes ? 0 : ((rows * 2 + 15) & ~(size_t)15)) /*xi*/ + (size_t)nT * 64 /*ctidx*/ + GEN_NTMAX * 4 /*nrow*/;
 }
 
+struct RowX {   // row knot coordinate = Ksh[xi[i]]
+    const uint16_t* idx; const double* K;
+    __device__ __forceinline__ double operator()(int i) const { return K[idx[i]]; }
+};
 struct ColX {   // column knot coordinate = Tsh[ctidx[r][lane]]
     const uint8_t* idx; const double* T;
     __device__ __forceinline__ double operator()(int i) const { return T[idx[i * 64]]; }
@@ -55,16 +63,18 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
     const bool cubic = method_is_cubic(method);
     const int minkn = method_min_knots(method);
 
+    const size_t rows = (size_t)nT * LK;
+    const size_t scratch = rows > (size_t)nT * 64 ? rows : (size_t)nT * 64;
     double* Ksh = reinterpret_cast<double*>(smem);
     double* Tsh = Ksh + nKmax;
-    double* xs = Tsh + GEN_NTMAX;
-    double* ys = xs + (size_t)nT * LK;
-    double* ss = ys + (size_t)nT * LK;
-    double* cps = ss + (size_t)nT * LK;
-    size_t scratch = (size_t)nT * LK > (size_t)nT * 64 ? (size_t)nT * LK : (size_t)nT * 64;
-    double* cz = cps + scratch;
-    double* cs = cz + (size_t)nT * 64;
-    uint8_t* ctidx = reinterpret_cast<uint8_t*>(cs + (size_t)nT * 64);
+    double* ys = Tsh + GEN_NTMAX;
+    double* cz = ys + rows;
+    double* xs = cz + (size_t)nT * 64;               // xs, ss, cps, cs exist only for the cubic methods
+    double* ss = xs + (cubic ? rows : 0);
+    double* cps = ss + (cubic ? rows : 0);
+    double* cs = cps + (cubic ? scratch : 0);
+    uint16_t* xi = reinterpret_cast<uint16_t*>(cs + (cubic ? (size_t)nT * 64 : 0));      // only without slopes
+    uint8_t* ctidx = reinterpret_cast<uint8_t*>(xi) + (cubic ? 0 : ((rows * 2 + 15) & ~(size_t)15));
     int* nrow = reinterpret_cast<int*>(ctidx + (size_t)nT * 64);
 
     // FILTER: a wave inspects 64 surfaces per load (lane i reads the tag of surface base+i) and only walks the
@@ -104,9 +114,9 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
             const int k = c0 + lane;
             const bool in = k < nKb;
             double v[GEN_NTMAX];
+            const double kx = in ? Kb[k] : 0.0;
 #pragma unroll
             for (int t = 0; t < GEN_NTMAX; ++t) v[t] = (t < nT && in) ? sb[(int64_t)t * nKb + k] : qnan();
-            const double kx = in ? Kb[k] : 0.0;
 #pragma unroll
             for (int t = 0; t < GEN_NTMAX; ++t) {
                 if (t < nT) {                                  // wave-uniform
@@ -114,7 +124,10 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
                     const unsigned long long m = __ballot(valid);
                     const int cnt = nrow[t];
                     const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                    if (valid) { xs[t * LK + rank] = kx; ys[t * LK + rank] = v[t]; }
+                    if (valid) {
+                        if (cubic) xs[t * LK + rank] = kx; else xi[t * LK + rank] = (uint16_t)k;
+                        ys[t * LK + rank] = v[t];
+                    }
                     if (lane == 0) nrow[t] = cnt + __popcll(m);
                 }
             }
@@ -146,9 +159,16 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
                 if (n > 0 && n < minkn) {
                     st |= IVS_ST_TOO_FEW_KNOTS;
                 } else if (n > 0) {
-                    CView x{xs + t * LK, 1}, y{ys + t * LK, 1}, s{ss + t * LK, 1};
-                    int j = (n == nKb) ? jfull : find_interval(x, n, xq);
-                    z = eval_method(method, x, y, s, n, j, xq);
+                    CView y{ys + t * LK, 1}, s{ss + t * LK, 1};
+                    if (cubic) {
+                        CView x{xs + t * LK, 1};
+                        int j = (n == nKb) ? jfull : find_interval(x, n, xq);
+                        z = eval_method(method, x, y, s, n, j, xq);
+                    } else {
+                        RowX x{xi + t * LK, Ksh};
+                        int j = (n == nKb) ? jfull : find_interval(x, n, xq);
+                        z = eval_method(method, x, y, s, n, j, xq);
+                    }
                 }
                 if (!__builtin_isnan(z)) {
                     cz[cn * 64 + lane] = z;
