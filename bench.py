@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=256, help="surfaces compared with the oracle after the timed region")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed region, also time the optional all-gather of the output shards (RCCL over xGMI); "
+                         "reported separately as 'gather', never part of 'value'")
     a = ap.parse_args()
 
     import numpy as np
@@ -149,6 +152,13 @@ def main():
         engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, a.method, out=out, status=status,
                              force_generic=a.force_generic, **kw)
 
+    # DVFS spin-up, before (and in addition to) the W warm-up steps: after any idle gap the first ~25 ms of launches
+    # run 10-25 % slower while the clocks ramp (tools/warm_probe.py: 4.55, 4.56, 4.13, 4.00, 3.83, 3.77, 3.70 ms ...),
+    # which would otherwise leak into the timed steps whenever W is small.  Untimed, fixed 100 ms of device time.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.1:
+        step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     kernel = engine.last_kernel()
@@ -173,6 +183,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
     assert int(status.max()) == 0
+
+    gather = None
+    if a.gather and dist:
+        # results normally stay sharded; the one optional collective is an all-gather of the output tiles
+        from iv_interpolation_amd import sharding
+        torch.cuda.synchronize(); dist.barrier()
+        g0 = time.perf_counter()
+        full = sharding.gather_outputs(out)
+        torch.cuda.synchronize(); dist.barrier()
+        gather = {"ms": (time.perf_counter() - g0) * 1e3, "bytes_per_rank": out.numel() * 8, "ranks": world,
+                  "gathered_shape": list(full.shape)}
+        del full
 
     # parity spot check (outside the timed region): a few surfaces against the oracle
     check = {}
@@ -220,6 +242,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch, "timing": "HIP events around each launch on the launch stream"},
             "parity_check": check,
         }
+        if gather:
+            res["gather"] = gather
         if world == 1 and not a.no_cpu_baseline and not ragged:
             res["cpu_baseline"] = cpu_baseline(a.method, nK, nT, mK, mT)
         print(json.dumps(res), flush=True)
