@@ -115,7 +115,7 @@ int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride
     int rc = check_launch("interp1d_prepare_kernel");
     if (rc) return rc;
     if (total_queries > 0) {
-        hipLaunchKernelGGL(ivs::interp1d_eval_kernel, dim3((unsigned)((total_queries + 255) / 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(ivs::interp1d_eval_kernel, dim3((unsigned)((total_queries + ivs::E1_ROWS - 1) / ivs::E1_ROWS)), dim3(256), 0, st, p);
         rc = check_launch("interp1d_eval_kernel");
     }
     return rc;
@@ -131,7 +131,7 @@ int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const 
     if (out_stride < total_queries) return fail(IVS_EINVAL, "ivs_ffill_index_batch: out_stride < total_queries");
     if ((total_queries + 255) / 256 > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_ffill_index_batch: too many rows");
     ivs::FfillParams p{src_pos, src_off, valid, valid_stride, n_cols, q_off, n_series, total_queries, idx_out, out_stride};
-    hipLaunchKernelGGL(ivs::ffill_index_kernel, dim3((unsigned)((total_queries + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(ivs::ffill_index_kernel, dim3((unsigned)((total_queries + ivs::F1_ROWS - 1) / ivs::F1_ROWS)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p);
     return check_launch("ffill_index_kernel");
 }

@@ -88,59 +88,76 @@ __device__ __forceinline__ int64_t series_of(const int64_t* off, int64_t S, int6
     return lo;
 }
 
-// Blocks of 256 consecutive output rows almost always lie inside ONE series (a symbol has thousands of minute rows):
-// two lanes find the series of the block's first and last row, and when they agree the series' compacted knots
+// Blocks of E1_ROWS consecutive output rows almost always lie inside ONE series (a symbol has thousands of minute
+// rows): two lanes find the series of the block's first and last row, and when they agree the series' compacted knots
 // (x, y, slopes) are staged in LDS once per channel, so the per-row binary search and the evaluation read LDS instead
 // of chasing 6-12 dependent global loads per row.  Blocks that straddle series, or series with more than
-// E1_STAGE knots, use the global arrays directly.
+// E1_STAGE knots, use the global arrays directly.  Four rows per thread amortise the staging (it cost as much as the
+// 256 evaluations it served).
 constexpr int E1_STAGE = 512;
+constexpr int E1_RPT = 4;                       // rows per thread
+constexpr int E1_ROWS = 256 * E1_RPT;           // rows per block
 
 __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
     __shared__ double sx[E1_STAGE], sy[E1_STAGE], ss[E1_STAGE];
     __shared__ int64_t s_edge[2];
     const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * 256;
-    const int64_t g = g0 + tid;
-    const bool active = g < p.total_q;
-    const int64_t g_last = g0 + 255 < p.total_q ? g0 + 255 : p.total_q - 1;
+    const int64_t g0 = (int64_t)blockIdx.x * E1_ROWS;
+    const int64_t g_last = g0 + E1_ROWS - 1 < p.total_q ? g0 + E1_ROWS - 1 : p.total_q - 1;
     if (tid == 0) s_edge[0] = series_of(p.q_off, p.S, g0);
     if (tid == 64) s_edge[1] = series_of(p.q_off, p.S, g_last);
     __syncthreads();
     const int64_t s_first = s_edge[0], s_last = s_edge[1];
     const bool one_series = s_first == s_last;                 // block-uniform
-    int64_t s = s_first;
-    if (!one_series && active) {                               // few candidates: walk
-        while (s < s_last && p.q_off[s + 1] <= g) ++s;
+    int64_t sr[E1_RPT]; double xq[E1_RPT]; bool active[E1_RPT];
+#pragma unroll
+    for (int u = 0; u < E1_RPT; ++u) {
+        const int64_t g = g0 + u * 256 + tid;
+        active[u] = g < p.total_q;
+        int64_t s = s_first;
+        if (!one_series && active[u]) {                        // few candidates: walk
+            while (s < s_last && p.q_off[s + 1] <= g) ++s;
+        }
+        sr[u] = s;
+        xq[u] = !active[u] ? qnan() : (p.xq ? p.xq[g] : (double)(g - p.q_off[s]));
     }
-    const int64_t a = p.knot_off[s];
-    const double xq = !active ? qnan() : (p.xq ? p.xq[g] : (double)(g - p.q_off[s]));
     const int method = p.method;
     const bool cubic = method_is_cubic(method);
     const bool lerp_method = method == IVS_LINEAR || method == IVS_SLINEAR;
     const int minkn = method_min_knots(method);
     for (int c = 0; c < p.C; ++c) {
-        const int n = p.wn[s * p.C + c];
-        const double* gx = p.wx + (int64_t)c * p.total_knots + a;
-        const double* gy = p.wy + (int64_t)c * p.total_knots + a;
-        const double* gs = p.ws + (int64_t)c * p.total_knots + a;
-        const bool staged = one_series && n > 0 && n <= E1_STAGE;      // block-uniform
+        const int64_t a1 = p.knot_off[s_first];
+        const int n1 = p.wn[s_first * p.C + c];
+        const bool staged = one_series && n1 > 0 && n1 <= E1_STAGE;      // block-uniform
         if (staged) {
+            const double* gx = p.wx + (int64_t)c * p.total_knots + a1;
+            const double* gy = p.wy + (int64_t)c * p.total_knots + a1;
+            const double* gs = p.ws + (int64_t)c * p.total_knots + a1;
             __syncthreads();                                   // previous channel's readers are done
-            for (int i = tid; i < n; i += 256) { sx[i] = gx[i]; sy[i] = gy[i]; if (cubic) ss[i] = gs[i]; }
+            for (int i = tid; i < n1; i += 256) { sx[i] = gx[i]; sy[i] = gy[i]; if (cubic) ss[i] = gs[i]; }
             __syncthreads();
             if (lerp_method) {     // np.interp's per-interval slope (dy/dx, IEEE division) once per knot instead of per row
-                for (int i = tid; i + 1 < n; i += 256) ss[i] = (sy[i + 1] - sy[i]) / (sx[i + 1] - sx[i]);
+                for (int i = tid; i + 1 < n1; i += 256) ss[i] = (sy[i + 1] - sy[i]) / (sx[i + 1] - sx[i]);
                 __syncthreads();
             }
         }
-        double r = qnan();
-        if (active && n > 0 && n >= minkn) {
-            CView x{staged ? sx : gx, 1}, y{staged ? sy : gy, 1}, sl{staged ? ss : gs, 1};
-            const int j = find_interval(x, n, xq);
-            if (staged && lerp_method) r = eval_linear_slopes(x, y, sl, n, j, xq, method == IVS_LINEAR);
-            else r = eval_method(method, x, y, sl, n, j, xq);
+#pragma unroll
+        for (int u = 0; u < E1_RPT; ++u) {
+            const int64_t s = sr[u];
+            const int64_t a = p.knot_off[s];
+            const int n = staged ? n1 : p.wn[s * p.C + c];
+            const double* gx = p.wx + (int64_t)c * p.total_knots + a;
+            const double* gy = p.wy + (int64_t)c * p.total_knots + a;
+            const double* gs = p.ws + (int64_t)c * p.total_knots + a;
+            double r = qnan();
+            if (active[u] && n > 0 && n >= minkn) {
+                CView x{staged ? sx : gx, 1}, y{staged ? sy : gy, 1}, sl{staged ? ss : gs, 1};
+                const int j = find_interval(x, n, xq[u]);
+                if (staged && lerp_method) r = eval_linear_slopes(x, y, sl, n, j, xq[u], method == IVS_LINEAR);
+                else r = eval_method(method, x, y, sl, n, j, xq[u]);
+            }
+            if (active[u]) p.out[c * p.out_stride + g0 + u * 256 + tid] = r;
         }
-        if (active) p.out[c * p.out_stride + g] = r;
     }
 }
 
@@ -149,52 +166,56 @@ struct FfillParams {
     const int64_t* q_off; int64_t S; int64_t total_q; int32_t* idx_out; int64_t out_stride;
 };
 
-// Same block structure as the eval kernel: the positions (and validity bytes) of the series' source rows are staged
-// in LDS when the block lies inside one series with at most F1_STAGE source rows.
+// Same block structure as the eval kernel (F1_ROWS rows per block, four per thread): the positions (and validity
+// bytes) of the series' source rows are staged in LDS when the block lies inside one series with at most F1_STAGE
+// source rows.
 constexpr int F1_STAGE = 512;
 constexpr int F1_COLS = 12;
+constexpr int F1_RPT = 4;
+constexpr int F1_ROWS = 256 * F1_RPT;
 
 __global__ __launch_bounds__(256) void ffill_index_kernel(FfillParams p) {
     __shared__ int64_t spos[F1_STAGE];
     __shared__ uint8_t sval[F1_COLS][F1_STAGE];
     __shared__ int64_t s_edge[2];
     const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * 256;
-    const int64_t g = g0 + tid;
-    const bool active = g < p.total_q;
-    const int64_t g_last = g0 + 255 < p.total_q ? g0 + 255 : p.total_q - 1;
+    const int64_t g0 = (int64_t)blockIdx.x * F1_ROWS;
+    const int64_t g_last = g0 + F1_ROWS - 1 < p.total_q ? g0 + F1_ROWS - 1 : p.total_q - 1;
     if (tid == 0) s_edge[0] = series_of(p.q_off, p.S, g0);
     if (tid == 64) s_edge[1] = series_of(p.q_off, p.S, g_last);
     __syncthreads();
     const int64_t s_first = s_edge[0], s_last = s_edge[1];
-    int64_t s = s_first;
-    if (s_first != s_last && active) {
-        while (s < s_last && p.q_off[s + 1] <= g) ++s;
-    }
-    const int64_t lo0 = p.src_off[s], hi0 = p.src_off[s + 1];
-    const int64_t nsrc = hi0 - lo0;
-    const bool staged = s_first == s_last && nsrc <= F1_STAGE && p.n_cols <= F1_COLS;      // block-uniform
+    const int64_t lo1 = p.src_off[s_first], n1 = p.src_off[s_first + 1] - lo1;
+    const bool staged = s_first == s_last && n1 <= F1_STAGE && p.n_cols <= F1_COLS;      // block-uniform
     if (staged) {
-        for (int i = tid; i < nsrc; i += 256) {
-            spos[i] = p.src_pos[lo0 + i];
-            for (int c = 0; c < p.n_cols; ++c) sval[c][i] = p.valid[c * p.valid_stride + lo0 + i];
+        for (int i = tid; i < n1; i += 256) {
+            spos[i] = p.src_pos[lo1 + i];
+            for (int c = 0; c < p.n_cols; ++c) sval[c][i] = p.valid[c * p.valid_stride + lo1 + i];
         }
         __syncthreads();
     }
-    if (!active) return;
-    const int64_t pos = g - p.q_off[s];
-    int64_t lo = 0, hi = nsrc;                                 // first local j with src_pos[j] > pos
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        const int64_t v = staged ? spos[mid] : p.src_pos[lo0 + mid];
-        if (v <= pos) lo = mid + 1; else hi = mid;
-    }
-    const int64_t jlast = lo - 1;
-    for (int c = 0; c < p.n_cols; ++c) {
-        int64_t j = jlast;
-        if (staged) { while (j >= 0 && !sval[c][j]) --j; }
-        else { const uint8_t* v = p.valid + c * p.valid_stride + lo0; while (j >= 0 && !v[j]) --j; }
-        p.idx_out[c * p.out_stride + g] = j >= 0 ? (int32_t)(lo0 + j) : -1;
+#pragma unroll
+    for (int u = 0; u < F1_RPT; ++u) {
+        const int64_t g = g0 + u * 256 + tid;
+        if (g >= p.total_q) continue;
+        int64_t s = s_first;
+        if (s_first != s_last) { while (s < s_last && p.q_off[s + 1] <= g) ++s; }
+        const int64_t lo0 = p.src_off[s];
+        const int64_t nsrc = p.src_off[s + 1] - lo0;
+        const int64_t pos = g - p.q_off[s];
+        int64_t lo = 0, hi = nsrc;                             // first local j with src_pos[j] > pos
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const int64_t v = staged ? spos[mid] : p.src_pos[lo0 + mid];
+            if (v <= pos) lo = mid + 1; else hi = mid;
+        }
+        const int64_t jlast = lo - 1;
+        for (int c = 0; c < p.n_cols; ++c) {
+            int64_t j = jlast;
+            if (staged) { while (j >= 0 && !sval[c][j]) --j; }
+            else { const uint8_t* v = p.valid + c * p.valid_stride + lo0; while (j >= 0 && !v[j]) --j; }
+            p.idx_out[c * p.out_stride + g] = j >= 0 ? (int32_t)(lo0 + j) : -1;
+        }
     }
 }
 
