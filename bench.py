@@ -75,13 +75,16 @@ def cpu_baseline(method, nK, nT, mK, mT, budget_s=20.0):
             "sample": f"{reps} x {n} surfaces of the same generator, vectorised NumPy oracle (oracle/ivs_oracle.py), method {method}"}
 
 
-def load_traffic(workload, method, kernel):
-    """HBM bytes per launch from the committed PMC pass (profiles/traffic.json), or None."""
+def load_traffic(workload, method, kernel, batch):
+    """HBM bytes per launch from the committed PMC pass (profiles/traffic.json), or None.  The pass was collected at the
+    batch size recorded with it; other batch sizes of the same workload scale linearly (every surface is streamed once)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            t = json.load(f)
-        return t.get(f"{workload}:{method}:{kernel}", {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(f"{workload}:{method}:{kernel}")
+        if not e:
+            return None
+        return e["hbm_bytes_per_launch"] * (batch / e.get("batch", batch))
     except Exception:
         return None
 
@@ -235,7 +238,7 @@ def main():
                        "quote_grid": [nK, nT], "output_grid": [mK, mT], "kernel": kernel,
                        "sharding": f"{world} x contiguous shard, no collective", "seed": synth.BASE_SEED},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(a.workload, a.method, kernel),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(a.workload, a.method, kernel, B),
                          "kernel": kernel, "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms),
                          "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2],
                          "device_copy_GBps": copy_gbps, "frac_of_device_copy": (achieved / copy_gbps) if copy_gbps else None,
