@@ -59,3 +59,20 @@ def test_shape_validation_codes_without_gpu():
     assert lib.ivs_interp1d_batch_f64(P, P, 5, P, 1, 1, 10, None, P, 10, P, 10, P, 0, P, 1 << 20, None) == -22   # stride < rows
     assert lib.ivs_interp1d_batch_f64(P, P, 10, P, 1, 1, 10, None, P, 10, P, 10, P, 0, P, 8, None) == -12        # workspace too small
     assert lib.ivs_candle_aggregate_f64(P, P, P, P, P, P, P, 1, 10, 0, P, P, P, P, P, P, P, None) == -22          # freq 0
+
+
+def test_bridge_validation_codes_without_gpu():
+    import ctypes as C
+    lib = _lib.load()
+    P = C.c_void_p(64)
+    call = lambda **kw: lib.ivs_bridge_candles_f64(  # noqa: E731
+        P, None, P, kw.get("S", 1), kw.get("rows", 100), kw.get("strategy", 0), 0.002, 1.5, P, kw.get("n_words", 1000),
+        P, P, kw.get("tail", P), P, kw.get("ws", 1 << 20), None)
+    assert call(strategy=7) == -22 and b"unknown strategy" in lib.ivs_last_error()
+    assert call(rows=-1) == -22
+    assert call(tail=None) == -22 and b"rng_tail" in lib.ivs_last_error()
+    assert call(ws=8) == -12                                            # workspace too small
+    assert lib.ivs_bridge_workspace_bytes(1000) >= 1000 * 20 and lib.ivs_bridge_workspace_bytes(-5) == lib.ivs_bridge_workspace_bytes(0)
+    assert lib.ivs_mt19937_words_u32(1, None, -1, None) == -22
+    assert lib.ivs_mt19937_words_u32(1, None, 0, None) == 0             # nothing to do
+    assert lib.ivs_mt19937_words_u32(1, None, 10, None) == -22          # null buffer
