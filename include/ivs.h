@@ -39,9 +39,10 @@ enum {
     IVS_ZERO        = 5, /* 'zero': order-0 spline = left knot's value; NaN outside the hull; >= 1 knot */
     IVS_PCHIP       = 6, /* 'pchip': PchipInterpolator; NaN left, extrapolates right; >= 2 knots */
     IVS_AKIMA       = 7, /* 'akima': Akima1DInterpolator; NaN outside the hull; >= 3 knots (scipy's 2-knot case is undefined) */
-    IVS_FROM_DERIVATIVES = 8 /* 'from_derivatives' / 'piecewise_polynomial': BPoly on values = Bernstein-form lines; NaN outside; >= 2 */
+    IVS_FROM_DERIVATIVES = 8, /* 'from_derivatives' / 'piecewise_polynomial': BPoly on values = Bernstein-form lines; NaN outside; >= 2 */
+    IVS_QUADRATIC   = 9  /* 'quadratic': interp1d(kind=2) = make_interp_spline(k=2), knots at the midpoints of the sites; NaN outside; >= 3 */
 };
-/* methods 0-3 run on the dense fast kernels; 4-8 on the generic surface kernel and the 1-D kernels */
+/* methods 0-3, 6, 7 run on the dense fast kernels; 4, 5, 8, 9 on the generic surface kernel; all on the 1-D kernels */
 
 /* return codes */
 enum {

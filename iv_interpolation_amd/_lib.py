@@ -18,10 +18,11 @@ ABI_VERSION = 1
 
 # pandas method names (reference core.py:61 forwards self.method) -> engine codes
 NEAREST, ZERO, PCHIP, AKIMA, FROM_DERIVATIVES = 4, 5, 6, 7, 8
+QUADRATIC = 9
 METHOD_CODES = {"linear": LINEAR, "index": LINEAR, "values": LINEAR,
                 "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
                 "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
-                "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES}
+                "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES, "quadratic": QUADRATIC}
 
 
 class EngineUnavailable(RuntimeError):

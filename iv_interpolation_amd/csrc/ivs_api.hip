@@ -37,7 +37,7 @@ int check_launch(const char* what) {
     return IVS_OK;
 }
 
-bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_FROM_DERIVATIVES; }
+bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_QUADRATIC; }
 
 int g_num_cu = 0;
 int num_cu() {

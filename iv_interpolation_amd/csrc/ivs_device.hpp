@@ -161,9 +161,10 @@ struct CView {
     __device__ __forceinline__ double operator()(int i) const { return p[i * stride]; }
 };
 
-// methods that evaluate a C1 piecewise cubic from knot slopes (not-a-knot solve, pchip or akima local rules)
+// methods that carry one precomputed value per knot besides y: the knot slopes of a C1 piecewise cubic (not-a-knot
+// solve, pchip or akima local rules) or the B-spline coefficients of the quadratic spline
 __host__ __device__ __forceinline__ bool method_is_cubic(int m) {
-    return m == IVS_CUBIC || m == IVS_CUBICSPLINE || m == IVS_PCHIP || m == IVS_AKIMA;
+    return m == IVS_CUBIC || m == IVS_CUBICSPLINE || m == IVS_PCHIP || m == IVS_AKIMA || m == IVS_QUADRATIC;
 }
 __device__ __forceinline__ bool method_extrapolates_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }
 __device__ __forceinline__ int method_min_knots(int m) {
@@ -172,6 +173,7 @@ __device__ __forceinline__ int method_min_knots(int m) {
         case IVS_CUBIC: return 4;
         case IVS_NEAREST: case IVS_ZERO: return 1;
         case IVS_AKIMA: return 3;
+        case IVS_QUADRATIC: return 3;
         default: return 2;
     }
 }
@@ -260,11 +262,60 @@ __device__ __forceinline__ void akima_slopes(const XA& x, const YA& y, SW& s, in
     }
 }
 
+// ---- 'quadratic': interp1d(kind=2) -> scipy make_interp_spline(k=2) (_bsplines.py): knot vector _not_a_knot for even
+// k = the midpoints of the data sites without the first and the last one, triple end knots.  Every site then sees
+// exactly three consecutive basis functions: the collocation matrix is tridiagonal (and totally positive: elimination
+// without pivoting is stable; scipy calls LAPACK gbsv).  Oracle: ivs_oracle.py quadratic_coeffs / quadratic_eval.
+template <class XA>
+__device__ __forceinline__ double quad_knot(const XA& x, int n, int j) {      // t_j, j = 0..n+2
+    if (j <= 2) return x(0);
+    if (j >= n) return x(n - 1);
+    return (x(j - 1) + x(j - 2)) / 2.0;                                       // mid_{j-2}
+}
+// the three quadratic B-splines that are non-zero on [t_ell, t_ell+1) at xv (de Boor's recurrence, scipy _deBoor_D)
+template <class XA>
+__device__ __forceinline__ void quad_basis(const XA& x, int n, int ell, double xv, double& h0, double& h1, double& h2) {
+    const double tm1 = quad_knot(x, n, ell - 1), t0 = quad_knot(x, n, ell), t1 = quad_knot(x, n, ell + 1),
+                 t2 = quad_knot(x, n, ell + 2);
+    const double w = 1.0 / (t1 - t0);
+    const double a0 = w * (t1 - xv), a1 = w * (xv - t0);                      // order 1
+    const double w1 = a0 / (t1 - tm1);
+    h0 = 0.0 + w1 * (t1 - xv);
+    h1 = w1 * (xv - tm1);
+    const double w2 = a1 / (t2 - t0);
+    h1 += w2 * (t2 - xv);
+    h2 = w2 * (xv - t0);
+}
+// B-spline coefficients into s (cp = scratch), n >= 3
+template <class XA, class YA, class SW, class CW>
+__device__ __forceinline__ void quadratic_coeffs(const XA& x, const YA& y, SW& s, CW& cp, int n) {
+    cp.set(0, 0.0); s.set(0, y(0));                                           // row 0 = [1, 0, ...]
+    for (int i = 1; i < n; ++i) {
+        double lo = 0.0, di = 1.0, up = 0.0;
+        if (i < n - 1) quad_basis(x, n, i + 1, x(i), lo, di, up);             // site i lies in knot interval ell = i + 1
+        const double w = di - lo * cp(i - 1);
+        cp.set(i, up / w);
+        s.set(i, (y(i) - lo * s(i - 1)) / w);
+    }
+    for (int i = n - 2; i >= 0; --i) s.set(i, s(i) - cp(i) * s(i + 1));
+}
+template <class XA, class SA>
+__device__ __forceinline__ double eval_quadratic(const XA& x, const SA& c, int n, int j, double xq) {
+    if (j < 0 || !(xq <= x(n - 1))) return qnan();
+    int q = n - 3;                                   // interior knots mid_1..mid_{n-3} that are <= xq
+    if (j < n - 1) { q = j - 1 + ((xq >= (x(j + 1) + x(j)) / 2.0) ? 1 : 0); q = q < 0 ? 0 : (q > n - 3 ? n - 3 : q); }
+    const int ell = q + 2;
+    double h0, h1, h2;
+    quad_basis(x, n, ell, xq, h0, h1, h2);
+    return h0 * c(ell - 2) + h1 * c(ell - 1) + h2 * c(ell);
+}
+
 // knot slopes of the method's interpolant (needs n >= method_min_knots and n >= 2)
 template <class XA, class YA, class SW, class CW>
 __device__ __forceinline__ void method_slopes(int method, const XA& x, const YA& y, SW& s, CW& scratch, int n) {
     if (method == IVS_PCHIP) pchip_slopes(x, y, s, n);
     else if (method == IVS_AKIMA) akima_slopes(x, y, s, n);
+    else if (method == IVS_QUADRATIC) quadratic_coeffs(x, y, s, scratch, n);
     else nak_slopes(x, y, s, scratch, n);
 }
 
@@ -277,6 +328,7 @@ __device__ __forceinline__ double eval_method(int method, const XA& x, const YA&
         case IVS_NEAREST: return eval_nearest(x, y, n, xq);
         case IVS_ZERO: return eval_zero(x, y, n, j, xq);
         case IVS_FROM_DERIVATIVES: return eval_bpoly_linear(x, y, n, j, xq);
+        case IVS_QUADRATIC: return eval_quadratic(x, s, n, j, xq);
         default: return eval_cubic(x, y, s, n, j, xq, method_extrapolates_right(method));
     }
 }

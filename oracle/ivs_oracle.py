@@ -48,8 +48,11 @@ AKIMA = 7        # pandas 'akima'      (Akima1DInterpolator: NaN outside hull; >
 FROM_DERIVATIVES = 8   # pandas 'from_derivatives' / 'piecewise_polynomial' (BPoly, values only = linear in
                        #                       Bernstein form, NaN outside hull)
 
+QUADRATIC = 9    # pandas 'quadratic'  (interp1d kind=2 -> make_interp_spline(k=2): quadratic B-spline with knots at the
+                 #                       midpoints of the data sites, NaN outside hull, >= 3 knots)
+
 METHOD_CODES = {
-    "linear": LINEAR, "index": LINEAR, "values": LINEAR,
+    "linear": LINEAR, "index": LINEAR, "values": LINEAR, "quadratic": QUADRATIC,
     "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
     "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
     "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES,
@@ -63,7 +66,7 @@ ST_TOO_FEW_KNOTS = 1   # the reference raises inside scipy -> interpolate_symbol
 def min_knots(method: int) -> int:
     """Fewest valid knots the reference accepts before scipy raises."""
     return {LINEAR: 0, CUBIC: 4, CUBICSPLINE: 2, SLINEAR: 2, NEAREST: 1, ZERO: 1, PCHIP: 2, AKIMA: 3,
-            FROM_DERIVATIVES: 2}[method]
+            FROM_DERIVATIVES: 2, QUADRATIC: 3}[method]
 
 
 # --------------------------------------------------------------------------- linear
@@ -263,6 +266,123 @@ def bpoly_linear_eval(xv, yv, xq):
     return np.where((j >= 0) & (xq <= xv[-1]), r, np.nan)
 
 
+# --------------------------------------------------------------------------- quadratic B-spline
+def quadratic_coeffs(x, y):
+    """make_interp_spline(x, y, k=2) (scipy _bsplines.py: knot vector _not_a_knot for even k = the midpoints of the data
+    sites with the first and the last one dropped, triple end knots; collocation system solved by LAPACK gbsv).
+    With those knots every data site sees exactly three consecutive basis functions: the collocation matrix is
+    TRIDIAGONAL (row 0 = [1, 0, ...], row n-1 = [..., 0, 1]) and totally positive, so plain elimination without
+    pivoting is stable.  Returns the n B-spline coefficients."""
+    x = np.asarray(x, np.float64); y = np.asarray(y, np.float64)
+    n = x.size
+    lo = np.zeros(n); di = np.ones(n); up = np.zeros(n)
+    if n > 2:                                   # interior rows, vectorised (_quad_row per site: same operations)
+        t = quadratic_knots(x)
+        ell = np.arange(1, n - 1) + 1
+        v = x[1:n - 1]
+        tm1, t0, t1, t2 = t[ell - 1], t[ell], t[ell + 1], t[ell + 2]
+        w = 1.0 / (t1 - t0)
+        a0 = w * (t1 - v); a1 = w * (v - t0)
+        w1 = a0 / (t1 - tm1)
+        lo[1:n - 1] = 0.0 + w1 * (t1 - v)
+        h1 = w1 * (v - tm1)
+        w2 = a1 / (t2 - t0)
+        di[1:n - 1] = h1 + w2 * (t2 - v)
+        up[1:n - 1] = w2 * (v - t0)
+    cp = np.zeros(n); dp = np.zeros(n)
+    cp[0] = up[0] / di[0]; dp[0] = y[0] / di[0]
+    for i in range(1, n):
+        w = di[i] - lo[i] * cp[i - 1]
+        cp[i] = up[i] / w
+        dp[i] = (y[i] - lo[i] * dp[i - 1]) / w
+    c = np.zeros(n)
+    c[n - 1] = dp[n - 1]
+    for i in range(n - 2, -1, -1):
+        c[i] = dp[i] - cp[i] * c[i + 1]
+    return c
+
+
+def _quad_knot(x, n, j):
+    """Knot t_j of the quadratic spline, j = 0..n+2: x_0 three times, mid_1..mid_{n-3}, x_{n-1} three times."""
+    if j <= 2:
+        return x[0]
+    if j >= n:
+        return x[n - 1]
+    i = j - 2                                   # interior knot mid_i, 1 <= i <= n-3
+    return (x[i + 1] + x[i]) / 2
+
+
+def _quad_basis(x, n, ell, xv):
+    """The three quadratic B-splines that are non-zero on [t_ell, t_ell+1) at xv (de Boor's recurrence as in scipy's
+    _deBoor_D): values of B_{ell-2}, B_{ell-1}, B_{ell}."""
+    t = lambda j: _quad_knot(x, n, j)           # noqa: E731
+    h = [1.0, 0.0, 0.0]
+    for j in range(1, 3):
+        hh = h[:j]
+        h[0] = 0.0
+        for m in range(1, j + 1):
+            ind = ell + m
+            xb = t(ind); xa = t(ind - j)
+            if xb == xa:
+                h[m] = 0.0
+                continue
+            w = hh[m - 1] / (xb - xa)
+            h[m - 1] += w * (xb - xv)
+            h[m] = w * (xv - xa)
+    return h
+
+
+def _quad_interval(x, n, xv):
+    """ell with t_ell <= xv < t_ell+1 (ell in 2..n-1; the last interval is closed on the right)."""
+    q = 0
+    for i in range(1, n - 2):                   # interior knots mid_1..mid_{n-3}
+        if (x[i + 1] + x[i]) / 2 <= xv:
+            q = i
+    return q + 2
+
+
+def _quad_row(x, n, i):
+    """Row i of the collocation matrix: (sub-diagonal, diagonal, super-diagonal)."""
+    if i == 0:
+        return 0.0, 1.0, 0.0
+    if i == n - 1:
+        return 0.0, 1.0, 0.0
+    ell = _quad_interval(x, n, x[i])
+    h = _quad_basis(x, n, ell, x[i])            # B_{ell-2..ell}; the row's columns are i-1, i, i+1 = ell-2.. for interior sites
+    assert ell - 2 == i - 1, (ell, i)
+    return h[0], h[1], h[2]
+
+
+def quadratic_knots(x):
+    """Full knot vector t_0..t_{n+2} (see _quad_knot)."""
+    x = np.asarray(x, np.float64)
+    n = x.size
+    mid = (x[1:] + x[:-1]) / 2
+    return np.r_[(x[0],) * 3, mid[1:n - 2], (x[n - 1],) * 3]
+
+
+def quadratic_eval(xv, yv, c, xq):
+    """Vectorised over the queries; same operation order per query as _quad_basis."""
+    xv = np.asarray(xv, np.float64); xq = np.asarray(xq, np.float64)
+    n = xv.size
+    t = quadratic_knots(xv)
+    v = xq.ravel()
+    inside = (v >= xv[0]) & (v <= xv[-1])                       # interp1d bounds_error=False: NaN outside the hull
+    vv = np.where(inside, v, xv[0])
+    ell = np.clip(np.searchsorted(t[3:n], vv, side="right"), 0, n - 3) + 2      # interior knots <= v
+    tm1, t0, t1, t2 = t[ell - 1], t[ell], t[ell + 1], t[ell + 2]
+    w = 1.0 / (t1 - t0)
+    a0 = w * (t1 - vv); a1 = w * (vv - t0)
+    w1 = a0 / (t1 - tm1)
+    h0 = 0.0 + w1 * (t1 - vv)
+    h1 = w1 * (vv - tm1)
+    w2 = a1 / (t2 - t0)
+    h1 = h1 + w2 * (t2 - vv)
+    h2 = w2 * (vv - t0)
+    r = h0 * c[ell - 2] + h1 * c[ell - 1] + h2 * c[ell]
+    return np.where(inside, r, np.nan).reshape(xq.shape)
+
+
 # --------------------------------------------------------------------------- 1-D operator
 def interp1d(xk, yk, xq, method: int):
     """One masked-knot 1-D interpolation (one channel of core.py:58-61, generalised to
@@ -291,6 +411,8 @@ def interp1d(xk, yk, xq, method: int):
         return zero_eval(xv, yv, xq), ST_OK
     if method == FROM_DERIVATIVES:
         return bpoly_linear_eval(xv, yv, xq), ST_OK
+    if method == QUADRATIC:
+        return quadratic_eval(xv, yv, quadratic_coeffs(xv, yv), xq), ST_OK
     if method == PCHIP:
         return hermite_eval(xv, yv, pchip_slopes(xv, yv), xq, extrapolate_right=True), ST_OK
     if method == AKIMA:

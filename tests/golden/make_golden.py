@@ -177,6 +177,19 @@ for k in range(40):
     add(f"fuzz{k:02d}", df, str(rf.choice(["linear", "cubic", "cubicspline", "slinear"])), int(rf.choice([2, 10])))
 
 
+# appended later, after the fuzz block, so that every earlier vector stays byte-identical
+for m in ("quadratic",):
+    add(f"x1_{m}", frame(12, 1), m)
+    dfx = frame(14, 5)
+    dfx.loc[4:6, "iv"] = np.nan; dfx.loc[0:1, "underlying_price"] = np.nan; dfx.loc[12:13, "time_to_maturity"] = np.nan
+    add(f"x5_nan_{m}", dfx, m)
+    add(f"x8_64to256_{m}", lattice_frame(p64, 80), m, 2)
+    for n in (2, 3, 4):
+        add(f"x9_few{n}_{m}", lattice_frame(np.arange(n) * 20, 99 + n), m, 2)
+    dfc = lattice_frame(np.arange(8) * 10, 120); dfc.loc[1:, "iv"] = np.nan
+    add(f"x9_chan_one_knot_{m}", dfc, m, 2)
+
+
 def enc(col: pd.Series):
     """Encode a column without pickling: returns dict of arrays + dtype tag."""
     dt = str(col.dtype)
@@ -233,7 +246,8 @@ def main():
             return None
         return r.loc[xq].to_numpy()
 
-    ALL_METHODS = ("linear", "cubic", "cubicspline", "slinear", "nearest", "zero", "pchip", "akima", "from_derivatives")
+    ALL_METHODS = ("linear", "cubic", "cubicspline", "slinear", "nearest", "zero", "pchip", "akima", "from_derivatives",
+                   "quadratic")
     r1 = np.random.default_rng(11)
     real = {}
     k = 0

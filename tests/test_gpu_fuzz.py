@@ -15,7 +15,8 @@ import ivs_oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
-           "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES}
+           "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES,
+           "quadratic": O.QUADRATIC}
 EXACT = ("linear", "nearest", "zero", "from_derivatives")
 
 

@@ -15,7 +15,8 @@ from golden_io import GOLDEN, SymbolCases, assert_symbol_frame  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
-           "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES}
+           "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES,
+           "quadratic": O.QUADRATIC}
 DENSE_METHODS = ["linear", "cubic", "cubicspline", "slinear", "pchip", "akima"]     # methods with dense and variable-shape kernels
 DENSE64_METHODS = DENSE_METHODS
 EXACT = ("linear", "nearest", "zero", "from_derivatives")               # bit-exact against the oracle / pandas
@@ -124,7 +125,7 @@ def test_config2_10k_surfaces_vs_oracle(method, force_generic):
     from iv_interpolation_amd import synth
     in_c = method in ("linear", "cubic", "cubicspline", "slinear", "pchip", "akima")
     # the three methods only the (slow, per-surface) NumPy oracle restates are checked on the first 2000 surfaces
-    d = synth.numpy_batch(10000 if in_c else 2000, 64, 16, seed=synth.BASE_SEED)
+    d = synth.numpy_batch(10000 if in_c else (400 if method == "quadratic" else 2000), 64, 16, seed=synth.BASE_SEED)
     Kq, Tq = synth.query_grids(64, 16)
     got, st, kern = _run(d, Kq, Tq, method, force_generic=force_generic)
     ref = None
