@@ -88,9 +88,12 @@ __device__ __forceinline__ void factor_tables_var(const double* X, int n, int la
         }
         const double pi = seg16_prefix_prod(in ? -al : 1.0, lane);
         const double psi = seg16_suffix_prod(in ? -cp : 1.0, lane);
-        if (in) {
+        {   // every slot is written: beyond n the NEUTRAL row (AL = -1, everything else 0) makes the forward sweep hold its
+            // value and the backward sweep harmless, so the sweeps need no per-step masks (the last system row has
+            // CP = 0, which cuts the backward recurrence off from whatever lies to its right)
             const int kl = d_sl(ir);
-            AL[kl] = al; CP[kl] = cp; PP[kl] = pp; QQ[kl] = qq; PM[kl] = pm; PI[kl] = pi; PSI[kl] = psi;
+            AL[kl] = in ? al : -1.0; CP[kl] = in ? cp : 0.0; PP[kl] = in ? pp : 0.0; QQ[kl] = in ? qq : 0.0;
+            PM[kl] = in ? pm : 0.0; PI[kl] = pi; PSI[kl] = psi;
             RDX[ir] = rdxc;
         }
         if (blk + 1 < NKB) {
@@ -142,15 +145,13 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
                 const double e = y[4] - y[3];
                 if (rs_seg == 0) { dA = dB; dB = e; }
             }
-            if (m < ln) {
-                const double r = PM[kp + m] * dM + PP[kp + m] * dA + QQ[kp + m] * dB;
-                prev = r - AL[kp + m] * prev;
-            }
+            const double r = PM[kp + m] * dM + PP[kp + m] * dA + QQ[kp + m] * dB;
+            prev = r - AL[kp + m] * prev;                      // neutral rows beyond n: r = 0, AL = -1 -> holds
             d[u][m] = prev;
             if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         endv[u] = prev;
-        pie[u] = ln > 0 ? PI[kp + ln - 1] : 1.0;
+        pie[u] = PI[kp + 15];                                  // neutral factors are 1: = the product up to the last knot
     }
     // ---- forward carries across the 4*NKB logical segments (0,1,2,3 of u = 0, then of u = 1, ...)
     double carry = 0.0;
@@ -175,15 +176,13 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
         double nxt = 0.0;
 #pragma unroll
         for (int m = 15; m >= 0; --m) {
-            if (m < ln) {
-                const double dp = d[u][m] + PI[kp + m] * din[u];
-                nxt = dp - CP[kp + m] * nxt;
-                d[u][m] = nxt;
-            }
+            const double dp = d[u][m] + PI[kp + m] * din[u];
+            nxt = dp - CP[kp + m] * nxt;                       // slots beyond n: finite garbage, cut off by CP[n-1] = 0
+            d[u][m] = nxt;
             if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
         }
-        firstv[u] = ln > 0 ? d[u][0] : 0.0;
-        psb[u] = ln > 0 ? PSI[kp] : 1.0;
+        firstv[u] = d[u][0];
+        psb[u] = PSI[kp];
     }
     carry = 0.0;
 #pragma unroll
@@ -202,8 +201,7 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
     for (int u = 0; u < NKB; ++u) {
         const int kp = 18 * (rs_seg + 4 * u);
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
-            if (m < len[u]) d[u][m] = d[u][m] + PSI[kp + m] * sin_[u];
+        for (int m = 0; m < 16; ++m) d[u][m] = d[u][m] + PSI[kp + m] * sin_[u];
     }
     __syncthreads();                                           // table reads done: the S plane may be overwritten
 #pragma unroll

@@ -101,9 +101,10 @@ __device__ __forceinline__ void factor_tables_var2(const double* X, int n, int l
     }
     const double pi = seg16_prefix_prod(in ? -al : 1.0, lane);
     const double psi = seg16_suffix_prod(in ? -cp : 1.0, lane);
-    if (in) {
+    {   // neutral rows beyond n (see factor_tables_var): the sweeps run unmasked
         const int kl = d_sl(ir);
-        AL[kl] = al; CP[kl] = cp; PP[kl] = pp; QQ[kl] = qq; PM[kl] = pm; PI[kl] = pi; PSI[kl] = psi;
+        AL[kl] = in ? al : -1.0; CP[kl] = in ? cp : 0.0; PP[kl] = in ? pp : 0.0; QQ[kl] = in ? qq : 0.0;
+        PM[kl] = in ? pm : 0.0; PI[kl] = pi; PSI[kl] = psi;
     }
 }
 
@@ -145,15 +146,13 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
                 const bool r0 = sg == 0;
                 dA = r0 ? dB : dA; dB = r0 ? e : dB;
             }
-            if (m < ln) {
-                const double r = PM[kp + m] * dM + PP[kp + m] * dA + QQ[kp + m] * dB;
-                prev = r - AL[kp + m] * prev;
-            }
+            const double r = PM[kp + m] * dM + PP[kp + m] * dA + QQ[kp + m] * dB;
+            prev = r - AL[kp + m] * prev;
             d[m] = prev;
             if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         endv = prev;
-        pie = ln > 0 ? PI[kp + ln - 1] : 1.0;
+        pie = PI[kp + 15];
     }
     // ---- forward carries: wave 0 chains its four segments and posts the row's value at the end of segment 3;
     // wave 1 picks it up after the barrier
@@ -178,16 +177,14 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
         double nxt = 0.0;
 #pragma unroll
         for (int m = 15; m >= 0; --m) {
-            if (m < ln) {
-                const double dp = d[m] + PI[kp + m] * din;
-                nxt = dp - CP[kp + m] * nxt;
-                d[m] = nxt;
-            }
+            const double dp = d[m] + PI[kp + m] * din;
+            nxt = dp - CP[kp + m] * nxt;
+            d[m] = nxt;
             if ((m & 3) == 0) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const double firstv = ln > 0 ? d[0] : 0.0;
-    const double psb = ln > 0 ? PSI[kp] : 1.0;
+    const double firstv = d[0];
+    const double psb = PSI[kp];
     auto bwd_chain = [&](double carry_in, double& si, double& t2) {
         si = rs_seg == 3 ? carry_in : 0.0;
         t2 = firstv + psb * si;
@@ -205,8 +202,7 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
     __syncthreads();
     if (w == 0) bwd_chain(XCH[X_BWD + rs_t], sin_, t2);
 #pragma unroll
-    for (int m = 0; m < 16; ++m)
-        if (m < ln) d[m] = d[m] + PSI[kp + m] * sin_;
+    for (int m = 0; m < 16; ++m) d[m] = d[m] + PSI[kp + m] * sin_;
     __syncthreads();                                           // table reads done: the S plane may be overwritten
     // all 16 slots of the segment are written (b128, conflict-free); those beyond n are never read
     double* srow = S + v2_row(rs_t) + kp;
