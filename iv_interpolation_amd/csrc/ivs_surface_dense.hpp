@@ -393,9 +393,8 @@ __device__ __forceinline__ void dense_maturity_slopes_local_rt(const double (&z)
 #pragma unroll
         for (int i = 1; i < DT; ++i) {
             const double w1 = TT[i * 4 + 1], w2 = TT[i * 4 + 2];
-            const double v = pchip_knot(F[i + 1], F[i + 2], w1, w2);
-            const double e = pchip_edge(F[i + 1], F[i], w1, w2);
-            s[i] = (i == nT - 1) ? e : v;                 // wave-uniform select
+            if (i == nT - 1) s[i] = pchip_edge(F[i + 1], F[i], w1, w2);      // wave-uniform branch: one of the two is computed
+            else s[i] = pchip_knot(F[i + 1], F[i + 2], w1, w2);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     } else {

@@ -284,12 +284,18 @@ __device__ __forceinline__ void segment_slopes(const double (&F)[19], const doub
             const double w1 = R1[kp + m], w2 = R2[kp + m];
             double v = pchip_knot(F[m + 1], F[m + 2], w1, w2);
             if (m == 0) { const double e = pchip_edge(F[2], F[3], w1, w2); v = kb == 0 ? e : v; }
-            const double e = pchip_edge(F[m + 1], F[m], w1, w2);        // one-sided rule at the last knot
-            v = (kb + m == n - 1) ? e : v;
-            d[m] = v;
+            d[m] = v;                                                   // knot n-1 is patched by pchip_last_slope
         }
         if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// pchip's one-sided rule at the last knot n-1 (run-time position): computed once per row from LDS instead of being
+// evaluated and selected away at every knot; the lane that owns knot n-1 overwrites its slope after the row is stored.
+__device__ __forceinline__ double pchip_last_slope(const double* yr, const double* R0, const double* R1, const double* R2, int n) {
+    const int k1 = d_sl(n - 1), k2 = d_sl(n - 2), k3 = d_sl(n - 3);
+    const double m2 = (yr[k1] - yr[k2]) * R0[k2], m3 = (yr[k2] - yr[k3]) * R0[k3];     // m_{n-2}, m_{n-3}
+    return pchip_edge(m2, m3, R1[k1], R2[k1]);
 }
 
 // Strike-direction slopes, local methods, n <= 64 (one wavefront per surface).  Tables alias the S plane.
@@ -320,6 +326,7 @@ __device__ __forceinline__ void dense_strike_slopes_local_var(const double* Y, d
         thr = 1e-9 * fmax;
     }
     segment_slopes<METHOD>(F, R1, R2, kb, kp, n, thr, d);
+    const double e_last = AK ? 0.0 : pchip_last_slope(Y + rs_t * RS, R0, R1, R2, n);
     __syncthreads();                               // table reads done: the S plane may be overwritten
     double* srow = S + rs_t * RS + kp;
 #pragma unroll
@@ -327,6 +334,7 @@ __device__ __forceinline__ void dense_strike_slopes_local_var(const double* Y, d
         double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
         *reinterpret_cast<double2*>(srow + 2 * c) = v;
     }
+    if (!AK && rs_seg == ((n - 1) >> 4)) S[rs_t * RS + d_sl(n - 1)] = e_last;     // same lane, after its row store
 }
 
 // Work list of a launch.  Ragged batches are classified once per call (var_classify_kernel) into one list per size

@@ -248,6 +248,7 @@ __device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, 
         segment_secants<false>(yr, R0, kb, kp, n, F);
     }
     segment_slopes<METHOD>(F, R1, R2, kb, kp, n, thr, d);
+    const double e_last = AK ? 0.0 : pchip_last_slope(yr, R0, R1, R2, n);
     __syncthreads();                               // table reads done: the S plane may be overwritten
     double* srow = S + v2_row(rs_t) + kp;
 #pragma unroll
@@ -255,6 +256,7 @@ __device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, 
         double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
         *reinterpret_cast<double2*>(srow + 2 * c) = v;
     }
+    if (!AK && sg == ((n - 1) >> 4)) S[v2_row(rs_t) + d_sl(n - 1)] = e_last;      // same lane, after its row store
 }
 
 template <int METHOD, bool WLDS, bool TSHARED = true>
