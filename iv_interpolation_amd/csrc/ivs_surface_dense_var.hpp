@@ -172,7 +172,6 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
 #pragma unroll
     for (int u = NKB - 1; u >= 0; --u) {
         const int kp = 18 * (rs_seg + 4 * u);
-        const int ln = len[u];
         double nxt = 0.0;
 #pragma unroll
         for (int m = 15; m >= 0; --m) {

@@ -214,11 +214,11 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
 }
 
 // Local methods (pchip, akima), 65..128 strikes: wave w owns the logical segments 4w .. 4w+3.  No carries cross the
-// waves (neighbouring quotes are read from LDS); akima's row maximum is taken over all 8 segments by letting every lane
-// also scan the partner segment of the other wave.
+// waves (neighbouring quotes are read from LDS); akima's row maximum over all 8 segments = the two waves' maxima,
+// exchanged through the LDS mailboxes (one barrier; scanning the partner wave's segment instead cost ~250 instructions).
 template <int METHOD>
-__device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, double* S, const double* Ksh, int n, int lane,
-                                                               int w) {
+__device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, double* S, const double* Ksh, double* XCH,
+                                                               int n, int lane, int w) {
     constexpr bool AK = METHOD == IVS_AKIMA;
     double* R0 = S;
     double* R1 = S + 152;
@@ -236,13 +236,13 @@ __device__ __forceinline__ void dense_strike_slopes_local_var2(const double* Y, 
     double F[19], d[16];
     double thr = 0.0;
     if (AK) {
-        const int sgp = rs_seg + 4 * (1 - w);
-        segment_secants<true>(yr, R0, 16 * sgp, 18 * sgp, n, F);
-        double fmax = segment_akima_fmax(F, 16 * sgp, n);
         segment_secants<true>(yr, R0, kb, kp, n, F);
-        fmax = __builtin_fmax(fmax, segment_akima_fmax(F, kb, n));
+        double fmax = segment_akima_fmax(F, kb, n);
         fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));
         fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
+        if (rs_seg == 0) XCH[X_FWD + 16 * w + rs_t] = fmax;                 // X_FWD / X_BWD: 32 contiguous slots
+        __syncthreads();
+        fmax = __builtin_fmax(fmax, XCH[X_FWD + 16 * (1 - w) + rs_t]);
         thr = 1e-9 * fmax;
     } else {
         segment_secants<false>(yr, R0, kb, kp, n, F);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                 dense_strike_slopes_var2(Y, S, Ksh, XCH, n, lane, w);
                 __syncthreads();
             } else if (d_is_local(METHOD)) {
-                dense_strike_slopes_local_var2<METHOD>(Y, S, Ksh, n, lane, w);
+                dense_strike_slopes_local_var2<METHOD>(Y, S, Ksh, XCH, n, lane, w);
                 __syncthreads();
             }
             if (!kq_shared) load_xq(Kqb);
