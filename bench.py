@@ -39,15 +39,22 @@ def algorithmic_bytes(B, nK, nT, mK, mT, total_strikes=None):
     return 8 * (nT * total_strikes + total_strikes + nT * B) + B * (8 * mT * mK + 8)
 
 
-def cpu_baseline(method, nK, nT, mK, mT, budget_s=20.0):
+def cpu_baseline(method, nK, nT, mK, mT, budget_s=20.0, sample=None):
     """The oracle ('port' of the reference's NumPy/SciPy arithmetic) timed on this box's host cores on a
     bounded sample of the same workload.  Uses the compiled C oracle with OpenMP when it is built,
-    else the vectorised NumPy oracle on one core."""
+    else the vectorised NumPy oracle on one core.  `sample` = (K, T, sigma, Kq, Tq, device results) of a few
+    surfaces of the timed batch: they are recomputed here and compared (returned as the second value)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ivs_oracle as O
     from iv_interpolation_amd import synth
     code = O.METHOD_CODES[method]
+    check = {}
+    if sample is not None:
+        Ks, Ts, sg, Kqs, Tqs, got = sample
+        ref, _ = O.surface_batch(Ks, Ts, sg, Kqs, Tqs, code)
+        check = {"surfaces": int(len(Ks)), "max_abs_diff_vs_oracle": float(np.nanmax(np.abs(got - ref))),
+                 "bit_exact": bool(np.array_equal(got, ref, equal_nan=True))}
     Kq, Tq = synth.query_grids(mK, mT, nT)
     try:
         import c_oracle
@@ -64,7 +71,7 @@ def cpu_baseline(method, nK, nT, mK, mT, budget_s=20.0):
             runner.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, code); reps += 1
         dt = time.perf_counter() - t0
         return {"value": n * reps / dt, "unit": "surfaces/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} x {n} surfaces of the same generator, C oracle (oracle/ivs_oracle_c.c, OpenMP), method {method}"}
+                "sample": f"{reps} x {n} surfaces of the same generator, C oracle (oracle/ivs_oracle_c.c, OpenMP), method {method}"}, check
     n = 2000
     d = synth.numpy_batch(n, nK, nT, seed=synth.BASE_SEED)
     t0 = time.perf_counter(); reps = 0
@@ -72,7 +79,7 @@ def cpu_baseline(method, nK, nT, mK, mT, budget_s=20.0):
         O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, code); reps += 1
     dt = time.perf_counter() - t0
     return {"value": n * reps / dt, "unit": "surfaces/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x {n} surfaces of the same generator, vectorised NumPy oracle (oracle/ivs_oracle.py), method {method}"}
+            "sample": f"{reps} x {n} surfaces of the same generator, vectorised NumPy oracle (oracle/ivs_oracle.py), method {method}"}, check
 
 
 def load_traffic(workload, method, kernel, batch):
@@ -199,17 +206,14 @@ def main():
                   "gathered_shape": list(full.shape)}
         del full
 
-    # parity spot check (outside the timed region): a few surfaces against the oracle
+    # parity spot check: a few surfaces are handed to the cpu_baseline leg below, the only place where bench.py touches
+    # the oracle (it is the checker there, never the thing measured)
     check = {}
-    if rank == 0 and a.check > 0 and not ragged:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import ivs_oracle as O
+    sample = None
+    if rank == 0 and world == 1 and a.check > 0 and not ragged and not a.no_cpu_baseline:
         idx = torch.linspace(0, B - 1, a.check, device="cuda").long()
-        ref, _ = O.surface_batch(d["K"][idx].cpu().numpy(), d["T"].cpu().numpy(), d["sigma"][idx].cpu().numpy(),
-                                 Kq_h, Tq_h, O.METHOD_CODES[a.method])
-        got = out[idx].cpu().numpy()
-        check = {"surfaces": a.check, "max_abs_diff_vs_oracle": float(np.nanmax(np.abs(got - ref))),
-                 "bit_exact": bool(np.array_equal(got, ref, equal_nan=True))}
+        sample = (d["K"][idx].cpu().numpy(), d["T"].cpu().numpy(), d["sigma"][idx].cpu().numpy(), Kq_h, Tq_h,
+                  out[idx].cpu().numpy())
 
     copy_gbps = None
     if rank == 0 and world == 1:
@@ -248,7 +252,7 @@ def main():
         if gather:
             res["gather"] = gather
         if world == 1 and not a.no_cpu_baseline and not ragged:
-            res["cpu_baseline"] = cpu_baseline(a.method, nK, nT, mK, mT)
+            res["cpu_baseline"], res["parity_check"] = cpu_baseline(a.method, nK, nT, mK, mT, sample=sample)
         print(json.dumps(res), flush=True)
     if dist:
         dist.destroy_process_group()
