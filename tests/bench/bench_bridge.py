@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Device-side rate of the IV -> OHLCV bridge: S symbols x m one-minute rows, stream generation and candle kernels
 timed separately with HIP events; the CPU oracle (the reference's per-row Python loop restated) on a small sample.
-    python tools/bench_bridge.py [--symbols 4096] [--rows 3781] [--strategy spread_simulation]"""
+    python tests/bench/bench_bridge.py [--symbols 4096] [--rows 3781] [--strategy spread_simulation]"""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import torch
 from iv_interpolation_amd import engine

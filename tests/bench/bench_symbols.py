@@ -5,7 +5,7 @@ rows, three interpolated channels + nine forward-filled columns.  Reports
   (2) end to end through IVInterpolator.interpolate_batch (DataFrames in, DataFrames out; includes packing, PCIe, pandas)
   (3) the CPU restatement of interpolate_symbol (oracle/ref_symbol.py, one core) on a bounded sample."""
 import argparse, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import torch

@@ -1,7 +1,8 @@
 """How the dense kernel (Moebius-scan pivots, segmented sweeps) and the generic kernel (serial Thomas) hold up against
 the oracle on badly spaced strike/maturity grids.  Diagnostic, run on the GPU box."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ivs_oracle as O
 from iv_interpolation_amd import engine
 r = np.random.default_rng(0)

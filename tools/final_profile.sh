@@ -27,8 +27,8 @@ done
 cd $R
 bash tools/pmc_run.sh cubic --steps 5 --warmup 1 > $O/pmc_cubic.txt 2>&1 || { tail -5 $O/pmc_cubic.txt; exit 1; }
 bash tools/pmc_run.sh cfg5 --steps 3 --warmup 1 --workload cfg5 > $O/pmc_cfg5.txt 2>&1 || { tail -5 $O/pmc_cfg5.txt; exit 1; }
-for s in spread_simulation price_as_midpoint simple_spread pipeline_inline trend_following; do python tools/bench_bridge.py --strategy $s > $O/bench_bridge_$s.json 2>> $O/bench_bridge.err || { tail -5 $O/bench_bridge.err; exit 1; }; done
-python tools/bench_symbols.py > $O/bench_symbols_linear.json 2> $O/bench_symbols.err || { tail -5 $O/bench_symbols.err; exit 1; }
+for s in spread_simulation price_as_midpoint simple_spread pipeline_inline trend_following; do python tests/bench/bench_bridge.py --strategy $s > $O/bench_bridge_$s.json 2>> $O/bench_bridge.err || { tail -5 $O/bench_bridge.err; exit 1; }; done
+python tests/bench/bench_symbols.py > $O/bench_symbols_linear.json 2> $O/bench_symbols.err || { tail -5 $O/bench_symbols.err; exit 1; }
 python tools/ragged_probe.py > $O/ragged_probe.txt 2>&1 || exit 1
 python - <<'PY'
 import json,glob,os
