@@ -158,9 +158,11 @@ def main():
     out = torch.empty((B, mT, mK), dtype=torch.float64, device="cuda")
     status = torch.empty((B,), dtype=torch.int32, device="cuda")
 
+    ws = engine.surface_workspace(B, ragged)          # caller-owned scratch: the timed call allocates nothing
+
     def step():
         engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, a.method, out=out, status=status,
-                             force_generic=a.force_generic, **kw)
+                             force_generic=a.force_generic, workspace=ws, **kw)
 
     # DVFS spin-up, before (and in addition to) the W warm-up steps: after any idle gap the first ~25 ms of launches
     # run 10-25 % slower while the clocks ramp (tools/warm_probe.py: 4.55, 4.56, 4.13, 4.00, 3.83, 3.77, 3.70 ms ...),

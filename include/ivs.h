@@ -11,7 +11,8 @@
  *     owned by the caller (e.g. torch tensor .data_ptr()) unless marked host;
  *   - fp64, row-major, contiguous; NaN in a value array means "missing quote" (not a knot);
  *   - asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
- *   - no allocation, no synchronisation inside a call (safe to capture in a hipGraph);
+ *   - no allocation, no synchronisation inside a call (safe to capture in a hipGraph): every entry point
+ *     that needs device scratch takes a caller-owned `workspace` sized by its *_workspace_bytes() function;
  *   - return 0 on success or a negative IVS_E* code; ivs_last_error() gives the text
  *     (thread local).  Numerical conditions (too few knots) are reported per item in
  *     the `status` array, never through the return code.
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IVS_ABI_VERSION 1
+#define IVS_ABI_VERSION 2
 
 /* interpolation methods: the pandas method names that core.py:61 forwards
  * (`merged[col].interpolate(method=self.method)`) and that this engine implements */
@@ -56,7 +57,8 @@ enum {
 /* per-item status bits written to `status` arrays */
 enum {
     IVS_ST_OK            = 0,
-    IVS_ST_TOO_FEW_KNOTS = 1  /* the reference's scipy call raises here -> interpolate_symbol returns None */
+    IVS_ST_TOO_FEW_KNOTS = 1, /* the reference's scipy call raises here -> interpolate_symbol returns None */
+    IVS_ST_BAD_SHAPE     = 2  /* ragged surface whose k_off span is negative or exceeds nK: skipped, outputs untouched */
 };
 
 int         ivs_version(void);        /* IVS_ABI_VERSION of the loaded library */
@@ -109,15 +111,22 @@ int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const 
  *   Kq/Tq  query grids of surface b at Kq + b*kq_stride / Tq + b*tq_stride (0 = shared), mK / mT points
  *   out    [B][mT][mK]
  *   status [B] or NULL; IVS_ST_* OR-ed over every 1-D solve of the surface
- *   flags  0, or IVS_FLAG_FORCE_GENERIC to bypass the dense fast path (testing / A-B timing)
+ *   flags  0, or IVS_FLAG_FORCE_GENERIC to bypass the dense fast path (testing / A-B timing); bits 8..15 =
+ *          IVS_FLAG_MAP_GROUPS(n): tuning override of the surface -> workgroup mapping of the 64x16 kernel (0 = default)
+ *   workspace  ivs_surface_workspace_bytes(B, ragged) bytes of device scratch (ragged = k_off != NULL): the
+ *          batch-wide maturity tables (read by the kernels through the scalar cache) and, for ragged batches, the
+ *          per-size-class work lists.  Contents are undefined after the call; concurrent calls need distinct workspaces.
  */
-enum { IVS_FLAG_FORCE_GENERIC = 1 };
+enum { IVS_FLAG_FORCE_GENERIC = 1, IVS_FLAG_ONE_PASS = 2 /* testing / A-B timing: skip the row-pass kernels (one-pass dense kernels instead) */ };
+#define IVS_FLAG_MAP_GROUPS(n) (((n) & 0xff) << 8)
+size_t ivs_surface_workspace_bytes(int64_t B, int32_t ragged);
 int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_stride, int32_t nK,
                           const double* T, int64_t t_stride, int32_t nT,
                           const double* sigma, int64_t B,
                           const double* Kq, int64_t kq_stride, int32_t mK,
                           const double* Tq, int64_t tq_stride, int32_t mT,
-                          double* out, int32_t* status, int32_t method, int32_t flags, void* stream);
+                          double* out, int32_t* status, int32_t method, int32_t flags,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Black-Scholes Greeks epilogue (reference src/interpolation/greeks.py:12-43, BlackScholesGreeks.calculate_greeks):

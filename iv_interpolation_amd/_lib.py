@@ -12,9 +12,15 @@ import os
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libivs.so")
 
 LINEAR, CUBIC, CUBICSPLINE, SLINEAR = 0, 1, 2, 3
-ST_OK, ST_TOO_FEW_KNOTS = 0, 1
+ST_OK, ST_TOO_FEW_KNOTS, ST_BAD_SHAPE = 0, 1, 2
 FLAG_FORCE_GENERIC = 1
-ABI_VERSION = 1
+
+
+def flag_map_groups(n: int) -> int:
+    """IVS_FLAG_MAP_GROUPS(n): tuning override of the 64x16 kernel's surface -> workgroup mapping (0 = default)."""
+    return (int(n) & 0xff) << 8
+
+ABI_VERSION = 2
 
 # pandas method names (reference core.py:61 forwards self.method) -> engine codes
 NEAREST, ZERO, PCHIP, AKIMA, FROM_DERIVATIVES = 4, 5, 6, 7, 8
@@ -54,8 +60,9 @@ SIGNATURES = {
                                          _p, C.c_size_t, _p]),
     "ivs_debug_stamps": (C.c_int, [_p, _i64]),
     "ivs_debug_last_grid": (_i64, []),
+    "ivs_surface_workspace_bytes": (_sz, [_i64, _i32]),
     "ivs_surface_batch_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i32,
-                                        _p, _p, _i32, _i32, _p]),
+                                        _p, _p, _i32, _i32, _p, _sz, _p]),
 }
 
 _lib = None

@@ -2,6 +2,7 @@
 // Argument validation happens here on the host; kernels assume validated shapes.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -13,15 +14,17 @@
 #include "ivs_interp1d.hpp"
 #include "ivs_surface_dense.hpp"
 #include "ivs_surface_dense_var2.hpp"
+#include "ivs_surface_pass.hpp"
 #include "ivs_surface_generic.hpp"
 
 namespace {
 
 thread_local char g_err[512] = "";
 thread_local const char* g_last_kernel = "";
-unsigned long long* g_stamp_buf = nullptr;   // device buffer for the diagnostic (stamped) dense kernel
-int64_t g_stamp_cap = 0;
-int64_t g_last_grid = 0;
+// diagnostics (ivs_debug_stamps): per calling thread, like the error string
+thread_local unsigned long long* g_stamp_buf = nullptr;   // device buffer for the diagnostic (stamped) dense kernel
+thread_local int64_t g_stamp_cap = 0;
+thread_local int64_t g_last_grid = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -39,17 +42,21 @@ int check_launch(const char* what) {
 
 bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_QUADRATIC; }
 
-int g_num_cu = 0;
-int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cu = prop.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
+// CU count of the CURRENT device, cached per device index (a process may drive several devices)
+std::atomic<int> g_cu[ivs::IVS_MAX_DEV];
+void current_device(int& dev, int& cus) {
+    dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const bool cached = dev >= 0 && dev < ivs::IVS_MAX_DEV;
+    cus = cached ? g_cu[dev].load(std::memory_order_relaxed) : 0;
+    if (cus <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+        cus = v > 0 ? v : 256;
+        if (cached) g_cu[dev].store(cus, std::memory_order_relaxed);
     }
-    return g_num_cu;
 }
+int num_cu() { int d, c; current_device(d, c); return c; }
 
 }  // namespace
 
@@ -130,6 +137,7 @@ int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const 
     if (!src_pos || !src_off || !valid || !q_off || !idx_out) return fail(IVS_EINVAL, "ivs_ffill_index_batch: null pointer");
     if (out_stride < total_queries) return fail(IVS_EINVAL, "ivs_ffill_index_batch: out_stride < total_queries");
     if ((total_queries + 255) / 256 > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_ffill_index_batch: too many rows");
+    if (valid_stride > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_ffill_index_batch: %lld source rows exceed the int32 gather index", (long long)valid_stride);
     ivs::FfillParams p{src_pos, src_off, valid, valid_stride, n_cols, q_off, n_series, total_queries, idx_out, out_stride};
     hipLaunchKernelGGL(ivs::ffill_index_kernel, dim3((unsigned)((total_queries + ivs::F1_ROWS - 1) / ivs::F1_ROWS)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p);
@@ -184,6 +192,7 @@ int ivs_bridge_candles_f64(const double* price, const double* volume, const int6
     if (workspace_bytes < ivs::bridge_ws_bytes(total_rows)) return fail(IVS_ENOMEM, "ivs_bridge_candles_f64: workspace too small");
     const int64_t nb = ivs::bridge_blocks(total_rows);
     if (nb > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_bridge_candles_f64: too many rows");
+    if (n_words > 0x7fffffffLL) return fail(IVS_ERANGE, "ivs_bridge_candles_f64: %lld words exceed the int32 per-row stream offsets", (long long)n_words);
     auto align64 = [](uintptr_t a) { return (a + 63) & ~(uintptr_t)63; };
     uintptr_t w = align64(reinterpret_cast<uintptr_t>(workspace));
     ivs::BridgeParams p;
@@ -239,12 +248,15 @@ int ivs_bs_greeks_f64(const double* S, const double* K, const double* T, const d
     return check_launch("greeks_kernel");
 }
 
+size_t ivs_surface_workspace_bytes(int64_t B, int32_t ragged) { return ivs::surface_ws_bytes(B, ragged != 0); }
+
 int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_stride, int32_t nK,
                           const double* T, int64_t t_stride, int32_t nT,
                           const double* sigma, int64_t B,
                           const double* Kq, int64_t kq_stride, int32_t mK,
                           const double* Tq, int64_t tq_stride, int32_t mT,
-                          double* out, int32_t* status, int32_t method, int32_t flags, void* stream) {
+                          double* out, int32_t* status, int32_t method, int32_t flags,
+                          void* workspace, size_t workspace_bytes, void* stream) {
     g_err[0] = 0;
     g_last_kernel = "";
     if (!valid_method(method)) return fail(IVS_EINVAL, "ivs_surface_batch_f64: unknown method %d", method);
@@ -256,28 +268,48 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
     if (!k_off && k_stride != 0 && k_stride < nK) return fail(IVS_EINVAL, "ivs_surface_batch_f64: k_stride < nK");
     if (t_stride < 0 || kq_stride < 0 || tq_stride < 0 || k_stride < 0)
         return fail(IVS_EINVAL, "ivs_surface_batch_f64: negative stride");
+    if (ivs::generic_lds_bytes(nK, nT, ivs::method_is_cubic(method)) > 160 * 1024)
+        return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d x nT=%d needs %zu B of LDS (> 160 KiB)", nK, nT,
+                    ivs::generic_lds_bytes(nK, nT, ivs::method_is_cubic(method)));
+    const size_t need = ivs::surface_ws_bytes(B, k_off != nullptr);
+    if (!workspace || workspace_bytes < need)
+        return fail(IVS_ENOMEM, "ivs_surface_batch_f64: workspace %zu < %zu bytes (ivs_surface_workspace_bytes)",
+                    workspace ? workspace_bytes : (size_t)0, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255)
+        return fail(IVS_EINVAL, "ivs_surface_batch_f64: workspace must be 256-byte aligned");
 
     ivs::SurfaceParams p;
     p.K = K; p.k_off = k_off; p.k_stride = k_stride; p.nK = nK;
     p.T = T; p.t_stride = t_stride; p.nT = nT;
-    p.sigma = sigma; p.B = B; p.map_groups = 1;
+    p.sigma = sigma; p.B = B; p.map_groups = 1; p.tqs = nullptr;
     p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;
     p.Tq = Tq; p.tq_stride = tq_stride; p.mT = mT;
     p.out = out; p.status = status; p.method = method;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    ivs::LaunchCtx cx;
+    current_device(cx.dev, cx.num_cu);
+    cx.st = static_cast<hipStream_t>(stream);
+    cx.ws = static_cast<unsigned char*>(workspace);
+    cx.ws_bytes = workspace_bytes;
+    cx.map_groups = (flags >> 8) & 0xff;
 
     if (!(flags & IVS_FLAG_FORCE_GENERIC)) {
         const char* name = nullptr;
-        int64_t need_blocks = (int64_t)num_cu() * 8;
+        int64_t need_blocks = (int64_t)cx.num_cu * 8;
         unsigned long long* dbg = (g_stamp_buf && g_stamp_cap >= need_blocks * ivs::D_NSTAMP) ? g_stamp_buf : nullptr;
-        int rc = ivs::launch_surface_dense(p, num_cu(), st, &name, dbg, &g_last_grid);
+        int rc = (dbg || (flags & IVS_FLAG_ONE_PASS)) ? 0 : ivs::launch_surface_pass(p, cx, &name);
+        if (rc == 1) {
+            g_last_kernel = name;
+            return check_launch(name);
+        }
+        if (rc < 0) return fail(IVS_ELAUNCH, "ivs_surface_batch_f64: row-pass dispatch failed");
+        rc = ivs::launch_surface_dense(p, cx, &name, dbg, &g_last_grid);
         if (rc == 1) {   // dispatched
             g_last_kernel = name;
             return check_launch(name);
         }
         if (rc < 0) return fail(IVS_ELAUNCH, "ivs_surface_batch_f64: dense dispatch failed");
         if (!g_stamp_buf) {
-            rc = ivs::launch_surface_dense_var(p, num_cu(), st, &name);
+            rc = ivs::launch_surface_dense_var(p, cx, &name);
             if (rc == 1) {
                 g_last_kernel = name;
                 return check_launch(name);
@@ -286,7 +318,7 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
         }
     }
 
-    if (!ivs::launch_surface_generic<false>(p, num_cu(), st))
+    if (!ivs::launch_surface_generic<false>(p, cx))
         return fail(IVS_ERANGE, "ivs_surface_batch_f64: nK=%d x nT=%d needs %zu B of LDS (> 160 KiB)", nK, nT,
                     ivs::generic_lds_bytes(nK, nT, ivs::method_is_cubic(method)));
     g_last_kernel = "surface_generic_kernel";

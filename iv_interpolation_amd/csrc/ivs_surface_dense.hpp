@@ -16,11 +16,21 @@
 // Surfaces that contain a NaN quote (or batches whose Tq is not ascending) are tagged with a
 // sentinel in out[b][0] and redone by the generic kernel in a second, filtered launch.
 #pragma once
+#include <atomic>
+#include <cstddef>
 #include <cstdlib>
 
 #include "ivs_surface_generic.hpp"
 
 namespace ivs {
+
+// IVS_ABLATE (tools/ablate_api.hip only, never the product build): what a phase costs in THROUGHPUT, measured by leaving
+// it out -- results are wrong by construction.  1 no strike slopes, 2 strike evaluation = one LDS read per row, 3 no
+// maturity solve, 4 one output row in 8 stored, 5 no prefetch after the first surface, 6 = 1+2+3 (staging + stores only).
+#ifndef IVS_ABLATE
+#define IVS_ABLATE 0
+#endif
+constexpr int ABL = IVS_ABLATE;
 
 constexpr int DK = 64, DT = 16;
 constexpr int D_RS = 72;                         // row stride in doubles (4 x (16 + 2))
@@ -50,6 +60,14 @@ template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_f64(double old, double src) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// old = 0.0 with full row / bank masks: bound_ctrl supplies the zero for lanes without a source, which saves the two
+// v_mov that would otherwise seed the destination with `old` before every pair of DPP moves
+template <int CTRL>
+__device__ __forceinline__ double dpp0_f64(double src) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 constexpr int DPP_ROW_SHL(int n) { return 0x100 | n; }   // lane i <- lane i+n (within a row of 16)
@@ -113,8 +131,9 @@ __device__ __forceinline__ void scan_mat2(double& p00, double& p01, double& p10,
     // `old` operand, so every lane multiplies unconditionally: no compare/select per step
 #define IVS_SCAN_STEP(CTRL, MASK)                                                              \
     {                                                                                          \
-        const double e = dpp_f64<CTRL, MASK>(1.0, p00), f = dpp_f64<CTRL, MASK>(0.0, p01);     \
-        const double g = dpp_f64<CTRL, MASK>(0.0, p10), h = dpp_f64<CTRL, MASK>(1.0, p11);     \
+        const double e = dpp_f64<CTRL, MASK>(1.0, p00), h = dpp_f64<CTRL, MASK>(1.0, p11);     \
+        const double f = MASK == 0xF ? dpp0_f64<CTRL>(p01) : dpp_f64<CTRL, MASK>(0.0, p01);    \
+        const double g = MASK == 0xF ? dpp0_f64<CTRL>(p10) : dpp_f64<CTRL, MASK>(0.0, p10);    \
         const double n00 = p00 * e + p01 * g, n01 = p00 * f + p01 * h;                         \
         const double n10 = p10 * e + p11 * g, n11 = p10 * f + p11 * h;                         \
         p00 = n00; p01 = n01; p10 = n10; p11 = n11;                                            \
@@ -156,7 +175,7 @@ __device__ __forceinline__ void factor_tables(const double* X, int lane, double&
     const double rb = refined_rcp(b);
     // g_i = a_i c_{i-1} / (b_i b_{i-1})
     const double crb = c * rb;                                          // c_i / b_i
-    const double crb_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, crb);
+    const double crb_prev = dpp0_f64<DPP_WAVE_SHR1>(crb);
     const double g = i == 0 ? 0.0 : a * rb * crb_prev;
     // omega_i = 1 - g_i / omega_{i-1}: prefix product of M_i = [[1,-g_i],[1,0]] (identity on lane 0)
     double p00 = 1.0, p01 = i == 0 ? 0.0 : -g, p10 = i == 0 ? 0.0 : 1.0, p11 = i == 0 ? 1.0 : 0.0;
@@ -165,10 +184,10 @@ __device__ __forceinline__ void factor_tables(const double* X, int lane, double&
     const double rw = i == 0 ? rb : den * rb * refined_rcp(num);   // 1 / w_i
     al = a * rw;
     cp = c * rw;
-    const double rdx_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, rdxc);   // 1/dx[i-1]
-    const double rdx_next = dpp_f64<DPP_WAVE_SHL1>(0.0, rdxc);   // 1/dx[i+1]
+    const double rdx_prev = dpp0_f64<DPP_WAVE_SHR1>(rdxc);   // 1/dx[i-1]
+    const double rdx_next = dpp0_f64<DPP_WAVE_SHL1>(rdxc);   // 1/dx[i+1]
     // (DPP reads need the SOURCE lane active: keep every cross-lane move outside divergent branches)
-    const double rdxmm = dpp_f64<DPP_WAVE_SHR1>(0.0, rdx_prev);  // 1/dx[i-2]
+    const double rdxmm = dpp0_f64<DPP_WAVE_SHR1>(rdx_prev);  // 1/dx[i-2]
     // edge rows need 1/d with d = x_{i+2}-x_i (row 0) or x_i - x_{i-2} (row N-1)
     const double d = i == 0 ? dxc + dxp : dxmm + dxm;
     const double rd = refined_rcp(d);
@@ -336,8 +355,8 @@ __device__ __forceinline__ void dense_strike_slopes_local(const double* Y, doubl
 }
 
 // The same slopes in the maturity direction: 16 knots per lane in registers, tables TT[i] = {r0, r1, r2, -}.
-template <int METHOD>
-__device__ __forceinline__ void dense_maturity_slopes_local(const double (&z)[DT], const double* TT, double (&s)[DT]) {
+template <int METHOD, class TP>
+__device__ __forceinline__ void dense_maturity_slopes_local(const double (&z)[DT], TP TT, double (&s)[DT]) {
     constexpr bool AK = METHOD == IVS_AKIMA;
     auto sec = [&](int i) { return (z[i + 1] - z[i]) * TT[i * 4]; };       // m_i, i = 0..14
     if (!AK) {
@@ -380,9 +399,8 @@ __device__ __forceinline__ void dense_maturity_slopes_local(const double (&z)[DT
 
 // Run-time maturity count nT (4..16): tables are all-zero beyond nT, so secants beyond the last knot come out 0 and are
 // replaced by akima's linear extension F(i) = 2 F(i-1) - F(i-2); pchip's one-sided rule moves to knot nT - 1.
-template <int METHOD>
-__device__ __forceinline__ void dense_maturity_slopes_local_rt(const double (&z)[DT], const double* TT, double (&s)[DT],
-                                                               int nT) {
+template <int METHOD, class TP>
+__device__ __forceinline__ void dense_maturity_slopes_local_rt(const double (&z)[DT], TP TT, double (&s)[DT], int nT) {
     constexpr bool AK = METHOD == IVS_AKIMA;
     double F[DT + 3];                               // F[i] = m_{i-2}
 #pragma unroll
@@ -472,7 +490,7 @@ __device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, 
     double din = 0.0, tot = d[15];
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
-        const double v = dpp_f64<DPP_ROW_SHR(1)>(0.0, tot);
+        const double v = dpp0_f64<DPP_ROW_SHR(1)>(tot);
         if (rs_seg == j) { din = v; tot = d[15] + pie * din; }
     }
     double nxt = 0.0;
@@ -488,7 +506,7 @@ __device__ __forceinline__ void dense_strike_slopes(const double* Y, double* S, 
     tot = d[0];
 #pragma unroll
     for (int j = 2; j >= 0; --j) {
-        const double v = dpp_f64<DPP_ROW_SHL(1)>(0.0, tot);
+        const double v = dpp0_f64<DPP_ROW_SHL(1)>(tot);
         if (rs_seg == j) { sin_ = v; tot = d[0] + psb * sin_; }
     }
 #pragma unroll
@@ -514,6 +532,23 @@ struct TqTables {
     unsigned long long iv_lo, iv_hi;      // rows per interval 0..7 / 8..14, one byte each
     __device__ __forceinline__ int n_iv(int j) const { return (int)(((j < 8 ? iv_lo : iv_hi) >> (8 * (j & 7))) & 0xffull); }
 };
+
+// Batch-wide maturity tables (T and Tq shared by every surface): written once per call by tq_tables_kernel into the
+// caller's workspace and read by the surface kernels through the SCALAR cache (constant address space => s_load):
+// uniform data costs neither LDS cycles (a broadcast ds_read_b128 occupies the LDS for 4 cycles) nor VGPRs.
+struct TqShared {
+    double TT[DT * 4];                    // per maturity knot: {PP, QQ, AL, CP} | {r0, r1, r2, -} | {T_j, T_j+1, 1/dt, dt}
+    double W[D_MAX_MT * 4];               // per query row: Hermite weights | {Tq, T_j, T_j+1, 1/dt}
+    double CP[DT];                        // CP_i once more, contiguous: the backward sweep re-requests it (two s_load_dwordx16)
+                                          // instead of keeping the forward sweep's copies alive in 32 SGPRs
+    double pm_last;
+    unsigned long long iv_lo, iv_hi;
+    int n_left, n_hold, n_nan, unsorted;
+};
+static_assert(offsetof(TqShared, W) == DT * 4 * 8 && offsetof(TqShared, CP) == (DT * 4 + D_MAX_MT * 4) * 8, "TT, W, CP back to back");
+#define IVS_CONST __attribute__((address_space(4)))
+typedef const double IVS_CONST* cdptr;
+__device__ __forceinline__ cdptr to_const(const double* p) { return (cdptr)p; }
 
 template <int NKB>
 __device__ __forceinline__ void factor_tables_var(const double* X, int n, int lane, double* AL, double* CP, double* PP,
@@ -610,30 +645,79 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
     __syncthreads();
 }
 
+// One wavefront per call: the T-phase of a batch whose T and Tq are shared, published as TqShared (see there).
+template <int METHOD, bool NTR>
+__global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared* o) {
+    __shared__ __attribute__((aligned(16))) double sm[8 * 72 + 64 + 64];
+    const int lane = threadIdx.x;
+    double* scratch = sm;                  // NTR: factor_tables_var scratch
+    double* Tsh = sm + 8 * 72;
+    double* TT = Tsh + 64;
+    TqTables tt;
+    dense_t_phase<METHOD, false, NTR>(p.T, p.Tq, p.mT, lane, Tsh, TT, nullptr, tt, p.nT, scratch);
+    if (lane < DT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o->TT[lane * 4 + c] = TT[lane * 4 + c];
+        o->CP[lane] = TT[lane * 4 + 3];
+    }
+    if (lane < p.mT) { o->W[lane * 4] = tt.w0; o->W[lane * 4 + 1] = tt.w1; o->W[lane * 4 + 2] = tt.w2; o->W[lane * 4 + 3] = tt.w3; }
+    if (lane == 0) {
+        o->pm_last = tt.pm_last; o->iv_lo = tt.iv_lo; o->iv_hi = tt.iv_hi;
+        o->n_left = tt.n_left; o->n_hold = tt.n_hold; o->n_nan = tt.n_nan; o->unsorted = tt.unsorted;
+    }
+}
+template <bool NTR>
+inline void launch_tq_tables(const SurfaceParams& p, TqShared* o, hipStream_t st) {
+#define IVS_TQ_CASE(M) case M: hipLaunchKernelGGL((tq_tables_kernel<M, NTR>), dim3(1), dim3(64), 0, st, p, o); break;
+    switch (p.method) {
+        IVS_TQ_CASE(IVS_LINEAR) IVS_TQ_CASE(IVS_CUBIC) IVS_TQ_CASE(IVS_CUBICSPLINE) IVS_TQ_CASE(IVS_SLINEAR)
+        IVS_TQ_CASE(IVS_PCHIP) IVS_TQ_CASE(IVS_AKIMA)
+        default: break;
+    }
+#undef IVS_TQ_CASE
+}
+// fills the uniform part of TqTables from the published tables (scalar loads)
+__device__ __forceinline__ void tq_from_shared(const void* tqs, TqTables& tt, const double*& TT, const double*& W) {
+    const TqShared* g = static_cast<const TqShared*>(tqs);
+    const TqShared IVS_CONST* c = (const TqShared IVS_CONST*)g;
+    tt.w0 = tt.w1 = tt.w2 = tt.w3 = 0.0;
+    tt.pm_last = c->pm_last; tt.iv_lo = c->iv_lo; tt.iv_hi = c->iv_hi;
+    tt.n_left = c->n_left; tt.n_hold = c->n_hold; tt.n_nan = c->n_nan; tt.unsorted = c->unsorted;
+    TT = g->TT; W = g->W;
+}
+
 // Maturity direction for one block of 64 output strikes (q-lane): z[t] = strike-pass value of row t at the lane's
 // strike.  Solves the lane's 16-knot system in registers (cubic) and walks the output rows class by class
 // (left-NaN rows, rows per maturity interval, hold rows, right-NaN rows), storing 512-B rows through a
 // wave-uniform base pointer.
 // RANGED: only the output rows [row_lo, row_hi) are produced (two-wavefront kernels split the rows).
 // NTR: run-time maturity count nT_rt (see dense_t_phase): masked system rows, three-tap last row, hold row = nT_rt - 1.
-template <int METHOD, bool WLDS, bool RANGED = false, bool NTR = false, class StampFn>
+// SM: TT and W point at the TqShared tables in global memory; every read of them is a scalar load (uniform index),
+// the next row's weights are requested while the current row is combined and stored.
+template <int METHOD, bool WLDS, bool RANGED = false, bool NTR = false, bool SM = false, class StampFn>
 __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const TqTables& tt, const double* TT,
                                                     const double* W, double* outb, int q0, int lane, bool act, int mT,
                                                     int mK, StampFn&& stamp, int row_lo = 0, int row_hi = 0,
                                                     int nT_rt = DT) {
     const int nT = NTR ? nT_rt : DT;
     constexpr bool CUB = d_is_hermite(METHOD);
-    constexpr bool w_lds = WLDS;
+    constexpr bool w_lds = WLDS && !SM;
     const double nanv = __builtin_nan("");
+    const cdptr cTT = to_const(TT), cW = to_const(W);          // SM only
+    const cdptr cCP = to_const(TT + DT * 4 + D_MAX_MT * 4);    // TqShared::CP (TT, W, CP are laid out back to back)
     // ---- maturity direction (q-lane, registers).  Row pointers are wave-uniform (scalar base),
     // the lane contributes only its 32-bit column offset.
     int tq = 0;
-    auto put = [&](int row, double v) {
-        double* rp = outb + (int64_t)row * mK + q0;           // uniform
+    double* rp = outb + q0;                                    // row tq of the output block: uniform running pointer
+    cdptr wp = cW;                                             // SM: weights of row tq
+    auto put = [&](int row, double v) {                        // row == tq at every call site
+        (void)row;
+        if (ABL == 4 && (row & 7) != 0) { asm volatile("" :: "v"(v)); return; }
         if (act) rp[lane] = v;
     };
+    auto adv = [&]() { ++tq; rp += mK; wp += 4; };
     auto mine = [&](int row) { return !RANGED || (row >= row_lo && row < row_hi); };      // wave-uniform
-    for (int c = 0; c < tt.n_left; ++c, ++tq) if (mine(tq)) put(tq, nanv);
+    for (int c = 0; c < tt.n_left; ++c, adv()) if (mine(tq)) put(tq, nanv);
     // weights of row tq: LDS broadcast (prefetched one row ahead) when mT <= 16, else readlane
     const double2* W2 = reinterpret_cast<const double2*>(W);
     double2 wa_n = double2{0.0, 0.0}, wb_n = double2{0.0, 0.0};
@@ -642,8 +726,21 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         if (RANGED && t0 < row_lo) t0 = row_lo < mT ? row_lo : 0;       // first row this wave will ask for
         wa_n = W2[2 * t0]; wb_n = W2[2 * t0 + 1];
     }
+    // SM: the next row's weights are requested one row ahead (the table has spare rows behind row mT - 1: TqShared::CP
+    // follows W, so the request past the last row needs no clamp).  A wave that skips rows (RANGED) reads at the use.
+    double wn0 = 0.0, wn1 = 0.0, wn2 = 0.0, wn3 = 0.0;
+    if (SM && !RANGED) { wn0 = wp[0]; wn1 = wp[1]; wn2 = wp[2]; wn3 = wp[3]; }
     auto weights = [&](int row, double& a0, double& a1, double& a2, double& a3) {
-        if (w_lds) {
+        (void)row;
+        if (SM && RANGED) {
+            a0 = wp[0]; a1 = wp[1]; a2 = wp[2]; a3 = wp[3];
+        } else if (SM) {
+            a0 = wn0; a1 = wn1; a2 = wn2; a3 = wn3;
+            // scalar loads return out of order (only lgkmcnt(0) is meaningful): take this row's values out of the
+            // counter BEFORE the next row's request is issued, so that the request flies during the row's arithmetic
+            asm volatile("" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3));
+            wn0 = wp[4]; wn1 = wp[5]; wn2 = wp[6]; wn3 = wp[7];
+        } else if (w_lds) {
             a0 = wa_n.x; a1 = wa_n.y; a2 = wb_n.x; a3 = wb_n.y;
             const int nx = row + 1 < mT ? row + 1 : row;      // prefetch the next row's weights
             wa_n = W2[2 * nx]; wb_n = W2[2 * nx + 1];
@@ -657,12 +754,43 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         double prev = 0.0;
         const double pm_last = NTR ? readlane_f64(tt.pm_last, 0) : 0.0;      // uniform -> SGPRs
         if (d_is_local(METHOD)) {
-            if (NTR) dense_maturity_slopes_local_rt<METHOD>(z, TT, s, nT);
-            else dense_maturity_slopes_local<METHOD>(z, TT, s);
+            if (SM) {
+                if (NTR) dense_maturity_slopes_local_rt<METHOD>(z, cTT, s, nT);
+                else dense_maturity_slopes_local<METHOD>(z, cTT, s);
+            } else {
+                if (NTR) dense_maturity_slopes_local_rt<METHOD>(z, TT, s, nT);
+                else dense_maturity_slopes_local<METHOD>(z, TT, s);
+            }
             // pin the slopes here: otherwise they (and, transitively, the strike evaluation with its 64 gathered
             // operands) are sunk into the row loops below and the live set overflows the register file
 #pragma unroll
             for (int i = 0; i < DT; ++i) asm volatile("" : "+v"(s[i]));
+        } else if (ABL == 3 || ABL == 6) {
+#pragma unroll
+            for (int i = 0; i < DT; ++i) s[i] = z[i] * 0.5;
+        } else if (SM) {   // forward / backward sweep with the table rows in SGPRs (scalar loads, grouped 4 rows at a time)
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const double pp = cTT[i * 4], qq = cTT[i * 4 + 1], al = cTT[i * 4 + 2];
+                if (!NTR) {
+                    const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                    prev = (pp * dA + qq * dB) - al * prev;
+                } else {
+                    const int ia = i == 0 ? 0 : i - 1, ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                    double r = pp * dA + qq * dB;
+                    if (i >= 3) r += ((i == nT - 1) ? pm_last : 0.0) * (z[i - 1] - z[i - 2]);     // scalar select
+                    prev = r - al * prev;
+                }
+                s[i] = prev;
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = DT - 2; i >= 0; --i) {
+                s[i] = s[i] - cCP[i] * s[i + 1];              // CP = 0 from the last row on
+                if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            }
         } else {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
             constexpr int LA = 4;
             double2 tpq[4], tac[4];
@@ -704,7 +832,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         stamp(4);
 #pragma unroll
         for (int jv = 0; jv < DT - 1; ++jv) {
-            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, adv()) {
                 if (!mine(tq)) continue;
                 double a0, a1, a2, a3;
                 weights(tq, a0, a1, a2, a3);
@@ -720,17 +848,18 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                 // operations per output row (same arithmetic as lerp_fast, hence the same bits)
                 const int n = tt.n_iv(jv);
                 if (n == 0) continue;
-                const double2 tj = *reinterpret_cast<const double2*>(TT + jv * 4);          // {T_j, T_j+1}
-                const double2 tr = *reinterpret_cast<const double2*>(TT + jv * 4 + 2);      // {1/dt, dt}
+                double2 tj, tr;                                                             // {T_j, T_j+1}, {1/dt, dt}
+                if (SM) { tj = double2{cTT[jv * 4], cTT[jv * 4 + 1]}; tr = double2{cTT[jv * 4 + 2], cTT[jv * 4 + 3]}; }
+                else { tj = *reinterpret_cast<const double2*>(TT + jv * 4); tr = *reinterpret_cast<const double2*>(TT + jv * 4 + 2); }
                 const double a = z[jv + 1] - z[jv];
                 const double q = a * tr.x;
                 const double rem = __builtin_fma(-q, tr.y, a);
                 const double slope = __builtin_fma(rem, tr.x, q);
                 const double aa = __builtin_fabs(a);
                 const bool slow_iv = !div_safe(tr.y) || !((a == 0.0) || (aa >= 0x1p-500 && aa <= 0x1p500));
-                for (int c = 0; c < n; ++c, ++tq) {
+                for (int c = 0; c < n; ++c, adv()) {
                     if (!mine(tq)) continue;
-                    const double xt = readlane_f64(tt.w0, tq);
+                    const double xt = SM ? wp[0] : readlane_f64(tt.w0, tq);
                     const double res = slope * (xt - tj.x) + z[jv];
                     const bool slow = slow_iv || __builtin_isnan(res);
                     double r = (tj.x == xt) ? z[jv] : res;
@@ -741,7 +870,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                 }
                 continue;
             }
-            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, ++tq) {
+            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, adv()) {
                 if (!mine(tq)) continue;
                 double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
                 weights(tq, xt, t0, t1, rdt);
@@ -763,8 +892,8 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
             asm volatile("" : "+v"(z_last));             // keeps LLVM from turning the chain into z[nT - 1] (= scratch array)
         }
     }
-    for (int c = 0; c < tt.n_hold; ++c, ++tq) if (mine(tq)) put(tq, z_last);
-    for (int c = 0; c < tt.n_nan; ++c, ++tq) if (mine(tq)) put(tq, nanv);
+    for (int c = 0; c < tt.n_hold; ++c, adv()) if (mine(tq)) put(tq, z_last);
+    for (int c = 0; c < tt.n_nan; ++c, adv()) if (mine(tq)) put(tq, nanv);
 }
 
 template <int METHOD, bool TSHARED, bool WLDS, bool STAMP = false>
@@ -798,8 +927,9 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
 
     TqTables tt;
     auto t_phase = [&](const double* Tb, const double* Tqb) { dense_t_phase<METHOD, WLDS>(Tb, Tqb, mT, lane, Tsh, TT, W, tt); };
-
-    if (t_shared) t_phase(p.T, p.Tq);
+    const double* TTp = TT;            // tables of the maturity pass: LDS, or the published TqShared (scalar cache)
+    const double* Wp = W;
+    if (t_shared) tq_from_shared(p.tqs, tt, TTp, Wp);
 
     // ---- prefetch registers (k-lane layout: chunk i of the surface = 16 B at i*1024 + lane*16)
     double2 pre[8];
@@ -859,9 +989,12 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         {   // next surface's loads fly during the whole computation; past the end the last surface is re-read
             // (harmless) so that the prefetch registers are written on every path
             const int64_t bn = b + b_step;
-            prefetch(bn < b_end ? bn : b);
+            if (ABL != 5) prefetch(bn < b_end ? bn : b);
         }
-        if (d_is_nak(METHOD)) {
+        if (d_is_nak(METHOD) && (ABL == 1 || ABL == 6)) {
+            RDX[lane] = 1.0;
+            __syncthreads();
+        } else if (d_is_nak(METHOD)) {
             dense_strike_slopes<STAMP>(Y, S, Ksh, RDX, lane, stamp);
             __syncthreads();
             stamp(2);
@@ -890,7 +1023,10 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
             const double x0 = Ksh[jj], x1 = Ksh[jj + 1];
             const int o0 = d_sl(jj), o1 = d_sl(jj + 1);
             double z[DT];
-            if (CUB) {
+            if (ABL == 2 || ABL == 6) {
+#pragma unroll
+                for (int r = 0; r < DT; ++r) z[r] = Y[r * D_RS + d_sl(lane)] + xq;
+            } else if (CUB) {
                 const bool ok = !left && ((xq <= xl) || d_extrap_right(METHOD));
                 const double u = xq - x0, t = u * RDX[jj], omt = 1.0 - t;
                 const double w0 = ok ? (1.0 + 2.0 * t) * omt * omt : nanv;
@@ -948,7 +1084,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
 #pragma unroll
                 for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
             }
-            if (act) dense_maturity_pass<METHOD, WLDS>(z, tt, TT, W, outb, q0, lane, true, mT, mK, stamp);
+            if (act) dense_maturity_pass<METHOD, WLDS, false, false, TSHARED>(z, tt, TTp, Wp, outb, q0, lane, true, mT, mK, stamp);
             stamp(5);
         }
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
@@ -960,43 +1096,69 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
     }
 }
 
-inline void set_max_lds(const void* fn) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+// ---- host side -------------------------------------------------------------------------------------------------
+// Everything a launcher needs from the entry point: the CURRENT device (index, CU count), the caller's stream and
+// workspace, and the tuning override of the surface -> workgroup mapping (flags bits 8..15).  No process-global state:
+// the kernel attribute that unlocks > 64 KiB of dynamic LDS is per device and is tracked per device below.
+struct LaunchCtx {
+    int dev = 0, num_cu = 256;
+    hipStream_t st = nullptr;
+    unsigned char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int map_groups = 0;
+};
+constexpr int IVS_MAX_DEV = 64;
+constexpr size_t WS_TQ_BYTES = 4096;                 // TqShared at offset 0
+constexpr size_t WS_COUNTS_BYTES = 256;              // ragged: per-class counters
+constexpr int V_NCLASS = 4;                          // ragged: work lists (one per size class), B items each
+static_assert(sizeof(TqShared) <= WS_TQ_BYTES, "TqShared must fit its workspace slot");
+inline size_t surface_ws_bytes(int64_t B, bool ragged) {
+    return WS_TQ_BYTES + (ragged ? WS_COUNTS_BYTES + (size_t)V_NCLASS * (size_t)(B < 0 ? 0 : B) * 16 : 0);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set once per (kernel slot, device)
+inline void ensure_max_lds(const void* fn, int slot, int dev) {
+    static std::atomic<unsigned long long> done[IVS_MAX_DEV];
+    const int d = (dev >= 0 && dev < IVS_MAX_DEV) ? dev : 0;
+    const unsigned long long bit = 1ull << (slot & 63);
+    if (dev < 0 || dev >= IVS_MAX_DEV || !(done[d].load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done[d].fetch_or(bit, std::memory_order_relaxed);
+    }
 }
 
 // Launch the generic kernel (FILTER selects the "only tagged surfaces" variant).  Returns false if the
 // shape does not fit in LDS.
 template <bool FILTER>
-inline bool launch_surface_generic(const SurfaceParams& p, int num_cu, hipStream_t st) {
+inline bool launch_surface_generic(const SurfaceParams& p, const LaunchCtx& cx) {
     if (p.nK > 65535) return false;                               // 16-bit strike indices
     const size_t lds = generic_lds_bytes(p.nK, p.nT, method_is_cubic(p.method));
     if (lds > 160 * 1024) return false;
-    static bool attr = false;
-    if (!attr) { set_max_lds(reinterpret_cast<const void*>(surface_generic_kernel<FILTER>)); attr = true; }
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(surface_generic_kernel<FILTER>), FILTER ? 1 : 0, cx.dev);
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
-    int64_t grid = (int64_t)num_cu * per_cu * 2;
+    int64_t grid = (int64_t)cx.num_cu * per_cu * 2;
     const int64_t work = FILTER ? (p.B + 63) / 64 : p.B;
     if (grid > work) grid = work;
-    hipLaunchKernelGGL(surface_generic_kernel<FILTER>, dim3((unsigned)grid), dim3(64), lds, st, p);
+    hipLaunchKernelGGL(surface_generic_kernel<FILTER>, dim3((unsigned)grid), dim3(64), lds, cx.st, p);
     return true;
 }
 
-// Dense dispatch.  Returns 1 if dispatched (dense kernel + filtered generic redo pass), 0 if the
-// shape is not covered by a dense kernel.
-// number of workgroup groups for a grid / batch (see the mapping comment in surface_dense_kernel); IVS_MAP_GROUPS
-// overrides it for experiments
-inline int dense_map_groups(int64_t grid, int64_t B) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("IVS_MAP_GROUPS"); forced = e ? atoi(e) : 0; }
+// number of workgroup groups for a grid / batch (see the mapping comment in surface_dense_kernel); `forced` > 0 is the
+// caller's IVS_FLAG_MAP_GROUPS override (experiments)
+inline int dense_map_groups(int64_t grid, int64_t B, int forced) {
     int r = forced > 0 ? forced : 8;
     while (r > 1 && (grid % r != 0 || B < (int64_t)64 * grid)) r >>= 1;      // small batches: one window
     return r < 1 ? 1 : r;
 }
 
-inline int launch_surface_dense(const SurfaceParams& p_in, int num_cu, hipStream_t st, const char** name,
+#ifndef IVS_DIAG_MINIMAL      // diagnostic builds (tools/pass_api.hip) skip the launchers that instantiate every kernel
+// Dense dispatch.  Returns 1 if dispatched (dense kernel + filtered generic redo pass), 0 if the
+// shape is not covered by a dense kernel.
+inline int launch_surface_dense(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name,
                                 unsigned long long* dbg = nullptr, int64_t* grid_out = nullptr) {
     SurfaceParams p = p_in;
+    hipStream_t st = cx.st;
     if (p.k_off || p.nK != DK || p.nT != DT) return 0;
     if (p.k_stride != 0 && p.k_stride < DK) return 0;
     if (reinterpret_cast<uintptr_t>(p.sigma) & 15) return 0;
@@ -1005,12 +1167,17 @@ inline int launch_surface_dense(const SurfaceParams& p_in, int num_cu, hipStream
     if (generic_lds_bytes(p.nK, p.nT) > 160 * 1024) return 0;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu > 8 ? 8 : per_cu;
-    int64_t grid = (int64_t)num_cu * per_cu;
+    int64_t grid = (int64_t)cx.num_cu * per_cu;
     if (grid > p.B) grid = p.B;
     if (grid_out) *grid_out = grid;
-    p.map_groups = dense_map_groups(grid, p.B);
+    p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);
     const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
     const bool wl = p.mT <= D_WLDS_MAX_MT;
+    if (tsh) {                                   // batch-wide maturity tables into the workspace, same stream
+        TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
+        launch_tq_tables<false>(p, tq, st);
+        p.tqs = tq;
+    }
     if (dbg) {   // diagnostic build: cubic and linear, shared T only
         if (!tsh) return 0;
         if (p.method == IVS_CUBIC) {
@@ -1043,8 +1210,10 @@ inline int launch_surface_dense(const SurfaceParams& p_in, int num_cu, hipStream
     }
 #undef IVS_DENSE_CASE
     if (hipGetLastError() != hipSuccess) return -1;
-    launch_surface_generic<true>(p, num_cu, st);     // redo pass for tagged surfaces (cheap when none are)
+    launch_surface_generic<true>(p, cx);     // redo pass for tagged surfaces (cheap when none are)
     return 1;
 }
+
+#endif  // IVS_DIAG_MINIMAL
 
 }  // namespace ivs

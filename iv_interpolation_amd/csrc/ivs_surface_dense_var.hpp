@@ -53,7 +53,7 @@ __device__ __forceinline__ void factor_tables_var(const double* X, int n, int la
         if (!in) { a = 0.0; b = 1.0; c = 0.0; }
         const double rb = refined_rcp(b);
         const double crb = c * rb;
-        double crb_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, crb);
+        double crb_prev = dpp0_f64<DPP_WAVE_SHR1>(crb);
         if (blk > 0 && lane == 0) crb_prev = carry_crb;
         const bool ident = first || !in;
         const double g = ident ? 0.0 : a * rb * crb_prev;
@@ -67,10 +67,10 @@ __device__ __forceinline__ void factor_tables_var(const double* X, int n, int la
         const double num = p00 + p01, den = p10 + p11;
         const double rw = first ? rb : den * rb * refined_rcp(num);
         const double al = a * rw, cp = c * rw;
-        double rdx_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, rdxc);
+        double rdx_prev = dpp0_f64<DPP_WAVE_SHR1>(rdxc);
         if (blk > 0 && lane == 0) rdx_prev = carry_rdx;
-        const double rdx_next = dpp_f64<DPP_WAVE_SHL1>(0.0, rdxc);          // only row 0 uses it (never crosses a block)
-        double rdxmm = dpp_f64<DPP_WAVE_SHR1>(0.0, rdx_prev);
+        const double rdx_next = dpp0_f64<DPP_WAVE_SHL1>(rdxc);          // only row 0 uses it (never crosses a block)
+        double rdxmm = dpp0_f64<DPP_WAVE_SHR1>(rdx_prev);
         if (blk > 0 && lane == 0) rdxmm = carry_rdx_prev;
         const double d = first ? dxc + dxp : dxmm + dxm;
         const double rd = refined_rcp(d);
@@ -161,11 +161,11 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
         double tot = endv[u] + pie[u] * di;
 #pragma unroll
         for (int j = 1; j < 4; ++j) {
-            const double v = dpp_f64<DPP_ROW_SHR(1)>(0.0, tot);
+            const double v = dpp0_f64<DPP_ROW_SHR(1)>(tot);
             if (rs_seg == j) { di = v; tot = endv[u] + pie[u] * di; }
         }
         din[u] = di;
-        carry = dpp_f64<DPP_QUAD_BCAST3>(0.0, tot);            // value at the end of logical segment 3 + 4u
+        carry = dpp0_f64<DPP_QUAD_BCAST3>(tot);            // value at the end of logical segment 3 + 4u
     }
     // ---- local backward sweeps (with the forward fix-up folded in)
     double firstv[NKB], psb[NKB], sin_[NKB];
@@ -190,11 +190,11 @@ __device__ __forceinline__ void dense_strike_slopes_var(const double* Y, double*
         double tot = firstv[u] + psb[u] * si;
 #pragma unroll
         for (int j = 2; j >= 0; --j) {
-            const double v = dpp_f64<DPP_ROW_SHL(1)>(0.0, tot);
+            const double v = dpp0_f64<DPP_ROW_SHL(1)>(tot);
             if (rs_seg == j) { si = v; tot = firstv[u] + psb[u] * si; }
         }
         sin_[u] = si;
-        carry = dpp_f64<DPP_QUAD_BCAST0>(0.0, tot);            // slope at the first knot of logical segment 4u
+        carry = dpp0_f64<DPP_QUAD_BCAST0>(tot);            // slope at the first knot of logical segment 4u
     }
 #pragma unroll
     for (int u = 0; u < NKB; ++u) {
@@ -358,6 +358,10 @@ __global__ __launch_bounds__(256) void var_classify_kernel(SurfaceParams p, VarI
             const int64_t b = b0 + 4 * tid + k;
             const int64_t nn = ko[k + 1] - ko[k];
             cls[k] = b >= p.B ? -1 : ((nn >= 4 && nn <= 64) ? 0 : ((nn >= 65 && nn <= 128) ? 1 : 2));
+            if (cls[k] == 2 && (nn < 0 || nn > p.nK)) {         // offsets no kernel can serve (the LDS carve is sized by nK)
+                cls[k] = -1;
+                if (p.status) p.status[b] = IVS_ST_BAD_SHAPE;
+            }
             if (cls[k] == 2)                                    // not served by a dense kernel: generic redo pass
                 reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)p.mT * p.mK)[0] = D_SENTINEL;
             if (cls[k] == 0) ++c[0];
@@ -414,7 +418,9 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
 
     TqTables tt;
     const int nT = p.nT;                                                   // 4..16, uniform over the batch
-    if (TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);       // once per workgroup
+    const double* TTp = TT;                // maturity tables: LDS (per-surface T) or the published TqShared (scalar cache)
+    const double* Wp = W;
+    if (TSHARED) tq_from_shared(p.tqs, tt, TTp, Wp);
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
 #pragma unroll
                     for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
                 }
-                if (act) dense_maturity_pass<METHOD, WLDS, false, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
+                if (act) dense_maturity_pass<METHOD, WLDS, false, true, TSHARED>(z, tt, TTp, Wp, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
             }
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         }

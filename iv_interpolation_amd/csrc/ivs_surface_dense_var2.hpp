@@ -63,7 +63,7 @@ __device__ __forceinline__ void factor_tables_var2(const double* X, int n, int l
     const double k62 = X[62], k63 = X[63], k64 = X[64];
     const double e_crb = (k63 - k62) * refined_rcp(2.0 * ((k63 - k62) + (k64 - k63)));    // same expression as block 0
     const double e_rdx63 = refined_rcp(k64 - k63), e_rdx62 = refined_rcp(k63 - k62);
-    double crb_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, crb);
+    double crb_prev = dpp0_f64<DPP_WAVE_SHR1>(crb);
     if (w > 0 && lane == 0) crb_prev = e_crb;
     const bool ident = first || !in;
     const double g = ident ? 0.0 : a * rb * crb_prev;
@@ -80,10 +80,10 @@ __device__ __forceinline__ void factor_tables_var2(const double* X, int n, int l
     const double num = p00 + p01, den = p10 + p11;
     const double rw = first ? rb : den * rb * refined_rcp(num);
     const double al = a * rw, cp = c * rw;
-    double rdx_prev = dpp_f64<DPP_WAVE_SHR1>(0.0, rdxc);
+    double rdx_prev = dpp0_f64<DPP_WAVE_SHR1>(rdxc);
     if (w > 0 && lane == 0) rdx_prev = e_rdx63;
-    const double rdx_next = dpp_f64<DPP_WAVE_SHL1>(0.0, rdxc);          // only row 0 uses it
-    double rdxmm = dpp_f64<DPP_WAVE_SHR1>(0.0, rdx_prev);
+    const double rdx_next = dpp0_f64<DPP_WAVE_SHL1>(rdxc);          // only row 0 uses it
+    double rdxmm = dpp0_f64<DPP_WAVE_SHR1>(rdx_prev);
     if (w > 0 && lane == 0) rdxmm = e_rdx62;
     const double d = first ? dxc + dxp : dxmm + dxm;
     const double rd = refined_rcp(d);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
         tot = endv + pie * di;
 #pragma unroll
         for (int j = 1; j < 4; ++j) {
-            const double v = dpp_f64<DPP_ROW_SHR(1)>(0.0, tot);
+            const double v = dpp0_f64<DPP_ROW_SHR(1)>(tot);
             if (rs_seg == j) { di = v; tot = endv + pie * di; }
         }
     };
@@ -190,7 +190,7 @@ __device__ __forceinline__ void dense_strike_slopes_var2(const double* Y, double
         t2 = firstv + psb * si;
 #pragma unroll
         for (int j = 2; j >= 0; --j) {
-            const double v = dpp_f64<DPP_ROW_SHL(1)>(0.0, t2);
+            const double v = dpp0_f64<DPP_ROW_SHL(1)>(t2);
             if (rs_seg == j) { si = v; t2 = firstv + psb * si; }
         }
     };
@@ -277,7 +277,9 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
 
     TqTables tt;
     const int nT = p.nT;                                                   // 4..16, uniform over the batch
-    if (TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T, p.Tq, mT, lane, Y, TT, W, tt, nT, S);   // both waves write identical tables
+    const double* TTp = TT;
+    const double* Wp = W;
+    if (TSHARED) tq_from_shared(p.tqs, tt, TTp, Wp);
 
     constexpr int XQ_REG = 4;
     double xq_reg[XQ_REG];
@@ -436,15 +438,15 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
                         for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
                     }
                     const int half = (mT + 1) >> 1;
-                    if (act) dense_maturity_pass<METHOD, WLDS, true, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp,
-                                                                           w == 0 ? 0 : half, w == 0 ? half : mT, nT);
+                    if (act) dense_maturity_pass<METHOD, WLDS, true, true, TSHARED>(z, tt, TTp, Wp, outb, q0, lane, true, mT, mK, nostamp,
+                                                                                    w == 0 ? 0 : half, w == 0 ? half : mT, nT);
                 } else {
                     strike_rows(std::integral_constant<int, DT>{}, 0);
                     if (d_is_local(METHOD)) {
 #pragma unroll
                         for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));
                     }
-                    if (act) dense_maturity_pass<METHOD, WLDS, false, true>(z, tt, TT, W, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
+                    if (act) dense_maturity_pass<METHOD, WLDS, false, true, TSHARED>(z, tt, TTp, Wp, outb, q0, lane, true, mT, mK, nostamp, 0, 0, nT);
                 }
             }
             if (p.status && threadIdx.x == 0) p.status[b] = IVS_ST_OK;
@@ -453,9 +455,13 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
     }
 }
 
+#ifndef IVS_DIAG_MINIMAL
 // Dispatch for variable strike counts: class 4..64 on the one-wavefront kernel, class 65..128 on the two-wavefront
 // kernel, then the filtered generic redo pass.  Returns 1 if dispatched, 0 if the batch is not covered.
-inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStream_t st, const char** name) {
+// Scratch (ragged work lists + counters, batch-wide maturity tables) comes from the caller's workspace: no allocation.
+inline int launch_surface_dense_var(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name) {
+    SurfaceParams p = p_in;
+    hipStream_t st = cx.st;
     if (p.nT < 4 || p.nT > DT || p.mT > D_MAX_MT) return 0;
     const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
     if (p.nK < 4 || p.nK > 128) return 0;
@@ -465,19 +471,21 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
     const bool wl = p.mT <= D_WLDS_MAX_MT;
     const bool need1 = p.k_off ? true : p.nK <= 64;
     const bool need2 = p.nK > 64;
-    // ragged batch: classify once into two work lists (stream-ordered scratch: 2 x B items + 2 counters)
+    if (tsh) {
+        TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
+        launch_tq_tables<true>(p, tq, st);
+        p.tqs = tq;
+    }
+    // ragged batch: classify once into one work list per size class (workspace: counters, then V_NCLASS x B items)
     VarItem* lists = nullptr;
     int32_t* counts = nullptr;
     if (p.k_off) {
         if (p.B > 0x7fffffffLL) return 0;
-        void* buf = nullptr;
-        const size_t bytes = (size_t)2 * p.B * sizeof(VarItem) + 64;
-        if (hipMallocAsync(&buf, bytes, st) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        lists = reinterpret_cast<VarItem*>(buf);
-        counts = reinterpret_cast<int32_t*>(lists + 2 * p.B);
-        if (hipMemsetAsync(counts, 0, 8, st) != hipSuccess) { (void)hipFreeAsync(buf, st); return -1; }
+        counts = reinterpret_cast<int32_t*>(cx.ws + WS_TQ_BYTES);
+        lists = reinterpret_cast<VarItem*>(cx.ws + WS_TQ_BYTES + WS_COUNTS_BYTES);
+        if (hipMemsetAsync(counts, 0, WS_COUNTS_BYTES, st) != hipSuccess) return -1;
         int64_t cb = (p.B + 1023) / 1024;
-        const int64_t cap = (int64_t)num_cu * 8;
+        const int64_t cap = (int64_t)cx.num_cu * 8;
         if (cb > cap) cb = cap;
         hipLaunchKernelGGL(var_classify_kernel, dim3((unsigned)cb), dim3(256), 0, st, p, lists, lists + p.B, counts);
     }
@@ -485,7 +493,7 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
     auto grid_for = [&](size_t lds) {
         int per_cu = (int)((160 * 1024) / lds);
         per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
-        int64_t g = (int64_t)num_cu * per_cu;
+        int64_t g = (int64_t)cx.num_cu * per_cu;
         return g > p.B ? p.B : g;
     };
 #define IVS_VAR_LAUNCH1(M)                                                                                           \
@@ -499,16 +507,8 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
     }
 #define IVS_VAR_LAUNCH2(M)                                                                                           \
     {                                                                                                                \
-        const size_t lds = dense_var2_lds_bytes(p.mT);                                                               \
+        const size_t lds = dense_var2_lds_bytes(p.mT);          /* 40 KB: below the 64 KiB default limit */          \
         const int64_t grid = grid_for(lds);                                                                          \
-        static bool attr = false;                                                                                    \
-        if (!attr) {                                                                                                 \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, true, true>));                    \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, false, true>));                   \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, true, false>));                   \
-            set_max_lds(reinterpret_cast<const void*>(surface_dense_var2_kernel<M, false, false>));                  \
-            attr = true;                                                                                             \
-        }                                                                                                            \
         if (wl && tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, true>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);     \
         else if (tsh) hipLaunchKernelGGL((surface_dense_var2_kernel<M, false, true>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);     \
         else if (wl) hipLaunchKernelGGL((surface_dense_var2_kernel<M, true, false>), dim3((unsigned)grid), dim3(128), lds, st, p, wl2);      \
@@ -533,11 +533,12 @@ inline int launch_surface_dense_var(const SurfaceParams& p, int num_cu, hipStrea
 #undef IVS_VAR_CASE
 #undef IVS_VAR_LAUNCH1
 #undef IVS_VAR_LAUNCH2
-    const bool launched = known && hipGetLastError() == hipSuccess;
-    if (launched) launch_surface_generic<true>(p, num_cu, st);
-    if (lists) (void)hipFreeAsync(lists, st);                 // stream-ordered: released after the kernels above
     if (!known) return 0;
+    const bool launched = hipGetLastError() == hipSuccess;
+    if (launched) launch_surface_generic<true>(p, cx);
     return launched ? 1 : -1;
 }
+
+#endif  // IVS_DIAG_MINIMAL
 
 }  // namespace ivs

@@ -21,6 +21,8 @@ struct SurfaceParams {
     const double* Tq; int64_t tq_stride; int mT;
     double* out; int32_t* status; int method;
     int map_groups;      // dense kernels: workgroups are split into this many groups, group r sweeps region r of the batch
+    const void* tqs;     // dense kernels, T and Tq shared by the batch: TqShared tables in the caller's workspace (written by
+                         // tq_tables_kernel on the same stream, read through the scalar cache)
 };
 
 constexpr int GEN_NTMAX = 32;
@@ -93,8 +95,15 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
         todo &= todo - 1;
         const int64_t b = FILTER ? ob * 64 + bit : ob;
         int64_t koff; int nKb;
-        if (p.k_off) { koff = p.k_off[b]; nKb = (int)(p.k_off[b + 1] - koff); }
-        else { koff = b * p.k_stride; nKb = nKmax; }
+        if (p.k_off) {
+            koff = p.k_off[b];
+            const int64_t span = p.k_off[b + 1] - koff;
+            if (span < 0 || span > nKmax) {                    // wave-uniform: offsets that the LDS carve cannot hold
+                if (p.status && lane == 0) p.status[b] = IVS_ST_BAD_SHAPE;
+                continue;
+            }
+            nKb = (int)span;
+        } else { koff = b * p.k_stride; nKb = nKmax; }
         const double* Kb = p.K + koff;
         const double* sb = p.k_off ? p.sigma + (int64_t)nT * koff : p.sigma + b * (int64_t)nT * nKmax;
         const double* Tb = p.T + b * p.t_stride;

@@ -1,0 +1,518 @@
+// Row-pass kernels: the not-a-knot fast path at 3 wavefronts per SIMD.
+//
+// The one-wavefront-per-surface kernels of ivs_surface_dense*.hpp keep the whole surface (two planes of 16 rows) in
+// LDS: 20 KB (64 strikes) or 40 KB (128 strikes), i.e. 8 wavefronts per CU -- and phase ablation (tools/ablate_api.hip,
+// profiles/r02/ablation.txt) shows that at 8 wavefronts the arithmetic is simply ADDED to the streaming time: the
+// skeleton (staging + stores) already runs at the device's streaming ceiling.  Here the strike direction is processed
+// in PASSES of RP rows, the planes hold one pass:
+//     64 strikes : 8 rows per pass, 2 passes, lane = (row, segment of 8 knots)     12.8 KB LDS, <= 168 VGPRs: 12 per CU
+//    128 strikes : 4 rows per pass, 4 passes, lane = (row, 16 segments of 8 knots)
+// The factorisation tables (one K-phase per surface) therefore get LDS of their own instead of aliasing the S plane.
+// Per pass: the rs-lanes sweep their 8 knots forward, the carries cross the 8 (16) segments of a row as a Kogge-Stone
+// scan of affine maps whose multipliers (products of segment products) are row independent and precomputed in the
+// K-phase, then the backward sweep, the backward scan and the fix-up; slopes go to the S plane, the q-lanes gather the
+// pass's rows into z[].  The maturity pass is dense_maturity_pass with the batch-wide tables in the scalar cache.
+// Layouts: Y plane row stride KCAP + 2 doubles, rows contiguous (b128 reads of the rs-lanes conflict-free for 64
+// strikes); S plane the same with the four 16-byte slots of a segment permuted by (segment >> 1) so that the b128 writes
+// of eight neighbouring segments hit eight different bank groups; tables at segment stride 10 (b128 broadcast reads of
+// 8 or 16 segments conflict-free), the scan multipliers in the two spare slots behind each table segment.
+// Scope: cubic / cubicspline, T and Tq shared by the batch, mK <= 64 (one block of output strikes: the pass structure
+// would recompute the slopes per block), 4..16 maturities; everything else stays on the one-pass kernels.
+#pragma once
+#include "ivs_surface_dense_var2.hpp"
+
+namespace ivs {
+
+template <int NKB>
+struct PassGeom {
+    static constexpr int NSEG = 8 * NKB;           // segments of 8 knots per row
+    static constexpr int RP = 64 / NSEG;           // rows per pass
+    static constexpr int NPASS = DT / RP;
+    static constexpr int KCAP = 64 * NKB;
+    static constexpr int RS = KCAP + 2;            // plane row stride (doubles)
+    static constexpr int PLANE = RP * RS;          // the two spare slots behind a row are read as y_{kb+8} of its last segment
+    static constexpr int TS = 10;                  // table segment stride (8 entries + 2 spare)
+    static constexpr int TN = NSEG * TS;           // one table
+    static constexpr int NSCAN = NKB == 1 ? 3 : 4; // carry scan steps (shift 1, 2, 4[, 8])
+};
+template <int NKB, bool VAR>
+__host__ __device__ constexpr size_t pass_lds_bytes() {
+    using G = PassGeom<NKB>;
+    // Y, S planes; AL CP PP QQ PI PSI [PM] tables; Ksh
+    return (size_t)(2 * G::PLANE + (VAR ? 7 : 6) * G::TN + G::KCAP) * 8;
+}
+
+__device__ __forceinline__ int p_tix(int k) { return (k >> 3) * 10 + (k & 7); }
+__device__ __forceinline__ int p_swz(int k) { return k ^ (((k >> 4) & 3) << 1); }     // S plane: slot c of segment s at c ^ (s >> 1)
+
+// inclusive prefix / suffix products within aligned groups of 8 lanes (two groups per DPP row: a shifted value that
+// comes from the neighbouring group is replaced by 1.0)
+__device__ __forceinline__ double seg8_prefix_prod(double v, int lane) {
+    const int i = lane & 7;
+    double t = dpp_f64<DPP_ROW_SHR(1)>(1.0, v); v *= i >= 1 ? t : 1.0;
+    t = dpp_f64<DPP_ROW_SHR(2)>(1.0, v); v *= i >= 2 ? t : 1.0;
+    t = dpp_f64<DPP_ROW_SHR(4)>(1.0, v); v *= i >= 4 ? t : 1.0;
+    return v;
+}
+__device__ __forceinline__ double seg8_suffix_prod(double v, int lane) {
+    const int i = lane & 7;
+    double t = dpp_f64<DPP_ROW_SHL(1)>(1.0, v); v *= i <= 6 ? t : 1.0;
+    t = dpp_f64<DPP_ROW_SHL(2)>(1.0, v); v *= i <= 5 ? t : 1.0;
+    t = dpp_f64<DPP_ROW_SHL(4)>(1.0, v); v *= i <= 3 ? t : 1.0;
+    return v;
+}
+
+// K-phase: factorisation tables of the not-a-knot system on n knots (n = KCAP when !VAR) at p_tix(k), the segment
+// products P_j = prod(-AL) / Q_j = prod(-CP) of every 8-knot segment, and from them the multipliers of the carry scans
+// (see pass_sweeps).  Ends with the tables visible to every lane.
+template <int NKB, bool VAR>
+__device__ __forceinline__ void pass_factor_tables(const double* X, int n, int lane, double* TB) {
+    using G = PassGeom<NKB>;
+    constexpr int TN = G::TN, NSEG = G::NSEG;
+    double* AL = TB; double* CP = TB + TN; double* PP = TB + 2 * TN; double* QQ = TB + 3 * TN;
+    double* PI = TB + 4 * TN; double* PSI = TB + 5 * TN; double* PM = TB + 6 * TN;
+    double c00 = 1.0, c01 = 0.0, c10 = 0.0, c11 = 1.0;          // product of all matrices of the previous blocks
+    double carry_crb = 0.0, carry_rdx = 0.0, carry_rdx_prev = 0.0;
+#pragma unroll
+    for (int blk = 0; blk < NKB; ++blk) {
+        const int ir = blk * 64 + lane;
+        const bool in = ir < n;
+        const int i = in ? ir : n - 1;
+        const double x0 = X[i];
+        const double xp = X[i + 1 < n ? i + 1 : n - 1];
+        const double xpp = X[i + 2 < n ? i + 2 : n - 1];
+        const double xm = X[i > 0 ? i - 1 : 0];
+        const double xmm = X[i > 1 ? i - 2 : 0];
+        const double dxc = xp - x0, dxm = x0 - xm, dxp = xpp - xp, dxmm = xm - xmm;
+        const double rdxc = refined_rcp(dxc);
+        const bool first = ir == 0, last = ir == n - 1;
+        double a, b, c;
+        if (first) { a = 0.0; b = dxp; c = dxc + dxp; }
+        else if (last) { a = dxmm + dxm; b = dxmm; c = 0.0; }
+        else { a = dxc; b = 2.0 * (dxm + dxc); c = dxm; }
+        if (!in) { a = 0.0; b = 1.0; c = 0.0; }
+        const double rb = refined_rcp(b);
+        const double crb = c * rb;
+        double crb_prev = dpp0_f64<DPP_WAVE_SHR1>(crb);
+        if (blk > 0 && lane == 0) crb_prev = carry_crb;
+        const bool ident = first || !in;
+        const double g = ident ? 0.0 : a * rb * crb_prev;
+        double p00 = 1.0, p01 = ident ? 0.0 : -g, p10 = ident ? 0.0 : 1.0, p11 = ident ? 1.0 : 0.0;
+        scan_mat2<64>(p00, p01, p10, p11, lane);
+        if (blk > 0) {                                           // append the previous blocks' product on the right
+            const double n00 = p00 * c00 + p01 * c10, n01 = p00 * c01 + p01 * c11;
+            const double n10 = p10 * c00 + p11 * c10, n11 = p10 * c01 + p11 * c11;
+            p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+        }
+        const double num = p00 + p01, den = p10 + p11;
+        const double rw = first ? rb : den * rb * refined_rcp(num);
+        const double al = a * rw, cp = c * rw;
+        double rdx_prev = dpp0_f64<DPP_WAVE_SHR1>(rdxc);
+        if (blk > 0 && lane == 0) rdx_prev = carry_rdx;
+        const double rdx_next = dpp0_f64<DPP_WAVE_SHL1>(rdxc);          // only row 0 uses it (never crosses a block)
+        double rdxmm = dpp0_f64<DPP_WAVE_SHR1>(rdx_prev);
+        if (blk > 0 && lane == 0) rdxmm = carry_rdx_prev;
+        const double d = first ? dxc + dxp : dxmm + dxm;
+        const double rd = refined_rcp(d);
+        double pm = 0.0, pp, qq;
+        if (first) {
+            pp = (dxc + 2.0 * d) * dxp * rdxc * rd * rw;         // * dy_0
+            qq = dxc * dxc * rdx_next * rd * rw;                 // * dy_1
+        } else if (last) {
+            pm = dxm * dxm * rdxmm * rd * rw;                    // * dy_{n-3}
+            pp = (2.0 * d + dxm) * dxmm * rdx_prev * rd * rw;    // * dy_{n-2}
+            qq = 0.0;
+            if (!VAR) { qq = pp; pp = pm; }                      // fixed n: the sweep feeds (dy_{n-3}, dy_{n-2}) to the last row
+        } else {
+            pp = 3.0 * dxc * rdx_prev * rw;                      // * dy_{i-1}
+            qq = 3.0 * dxm * rdxc * rw;                          // * dy_i
+        }
+        const double pi = seg8_prefix_prod(in ? -al : 1.0, lane);
+        const double psi = seg8_suffix_prod(in ? -cp : 1.0, lane);
+        {   // beyond n the NEUTRAL row (AL = -1, everything else 0): the forward sweep holds its value, the last system
+            // row's CP = 0 cuts the backward recurrence off from whatever lies to its right (see factor_tables_var)
+            const int kl = p_tix(ir);
+            AL[kl] = in ? al : -1.0; CP[kl] = in ? cp : 0.0; PP[kl] = in ? pp : 0.0; QQ[kl] = in ? qq : 0.0;
+            if (VAR) PM[kl] = in ? pm : 0.0;
+            PI[kl] = pi; PSI[kl] = psi;
+            if ((lane & 7) == 7) PI[(ir >> 3) * 10 + 8] = pi;                  // P_j: product of (-AL) over segment j (spare slot)
+            if ((lane & 7) == 0) PSI[(ir >> 3) * 10 + 8] = in ? psi : 0.0;     // Q_j: product of (-CP)
+        }
+        if (blk + 1 < NKB) {
+            c00 = readlane_f64(p00, 63); c01 = readlane_f64(p01, 63); c10 = readlane_f64(p10, 63); c11 = readlane_f64(p11, 63);
+            carry_crb = readlane_f64(crb, 63); carry_rdx = readlane_f64(rdxc, 63); carry_rdx_prev = readlane_f64(rdx_prev, 63);
+        }
+    }
+    __syncthreads();
+    {   // scan multipliers: forward step s (1, 2, 4, 8) multiplies the value 2^s segments to the left by
+        // P_j P_{j-1} .. P_{j-s+1}; 0 where no such segment exists (it also silences the DPP sources of the neighbouring
+        // row when two rows share a DPP row).  Backward: Q_j .. Q_{j+s-1} and the segment to the right.
+        const int j = lane < NSEG ? lane : NSEG - 1;
+        double pw = lane < NSEG ? PI[j * 10 + 8] : 1.0, qw = lane < NSEG ? PSI[j * 10 + 8] : 1.0;
+        double fm[4], bm[4];
+#pragma unroll
+        for (int s = 0; s < G::NSCAN; ++s) {
+            fm[s] = j >= (1 << s) ? pw : 0.0;
+            bm[s] = j + (1 << s) <= NSEG - 1 ? qw : 0.0;
+            if (s == 0) { pw *= dpp_f64<DPP_ROW_SHR(1)>(1.0, pw); qw *= dpp_f64<DPP_ROW_SHL(1)>(1.0, qw); }
+            if (s == 1) { pw *= dpp_f64<DPP_ROW_SHR(2)>(1.0, pw); qw *= dpp_f64<DPP_ROW_SHL(2)>(1.0, qw); }
+            if (s == 2) { pw *= dpp_f64<DPP_ROW_SHR(4)>(1.0, pw); qw *= dpp_f64<DPP_ROW_SHL(4)>(1.0, qw); }
+        }
+        if (lane < NSEG) {      // spare slots 8, 9 of segment j in the AL / CP / PP / QQ tables
+            AL[j * 10 + 8] = fm[0]; AL[j * 10 + 9] = fm[1]; CP[j * 10 + 8] = fm[2];
+            PP[j * 10 + 8] = bm[0]; PP[j * 10 + 9] = bm[1]; QQ[j * 10 + 8] = bm[2];
+            if (NKB > 1) { CP[j * 10 + 9] = fm[3]; QQ[j * 10 + 9] = bm[3]; }
+        }
+    }
+    __syncthreads();
+}
+
+// One pass: slopes of the RP rows staged in Yp -> Sp.  All 64 lanes; no barrier inside (the caller brackets it).
+template <int NKB, bool VAR>
+__device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const double* TB, int lane) {
+    using G = PassGeom<NKB>;
+    constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS;
+    const double* AL = TB; const double* CP = TB + TN; const double* PP = TB + 2 * TN; const double* QQ = TB + 3 * TN;
+    const double* PI = TB + 4 * TN; const double* PSI = TB + 5 * TN; const double* PM = TB + 6 * TN;
+    const int tl = lane / NSEG, seg = lane % NSEG;
+    const int kb = seg * 8, tb = seg * 10;
+    const bool s_first = seg == 0, s_last = seg == NSEG - 1;
+    const double* yr = Yp + tl * RS + kb;
+    double y[11];                                   // y[j] = y_{kb + j - 2}
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(yr + 2 * c);
+        y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
+    }
+    {   // the two knots to the left (segment 0: re-reads its own first pair, selected away / multiplied by 0 below)
+        const double2 v = *reinterpret_cast<const double2*>(s_first ? yr : yr - 2);
+        y[0] = v.x; y[1] = v.y;
+    }
+    y[10] = yr[8];                                  // last segment: the spare slot behind the row (kept finite)
+    auto tab2 = [&](const double* T, int m) { return *reinterpret_cast<const double2*>(T + tb + m); };   // entries m, m+1
+    double d[8];
+    double prev = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < 8; mm += 2) {
+        const double2 tpp = tab2(PP, mm), tqq = tab2(QQ, mm), tal = tab2(AL, mm);
+        double2 tpm = double2{0.0, 0.0};
+        if (VAR) tpm = tab2(PM, mm);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = mm + u;
+            double dM = y[m + 1] - y[m], dA = y[m + 2] - y[m + 1], dB = y[m + 3] - y[m + 2];   // dy_{i-2}, dy_{i-1}, dy_i
+            if (m == 0) { const double e = y[4] - y[3]; dA = s_first ? dB : dA; dB = s_first ? e : dB; }      // row 0: (dy_0, dy_1)
+            if (!VAR && m == 7) { dB = s_last ? dA : dB; dA = s_last ? dM : dA; }                             // row n-1: (dy_{n-3}, dy_{n-2})
+            double r = (u ? tpp.y : tpp.x) * dA + (u ? tqq.y : tqq.x) * dB;
+            if (VAR) r += (u ? tpm.y : tpm.x) * dM;
+            prev = r - (u ? tal.y : tal.x) * prev;
+            d[m] = prev;
+        }
+        if (mm == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- forward carries: tot_j = E_j + P_j tot_{j-1} over the segments of the row, Kogge-Stone on the E part
+    const double2 fm01 = *reinterpret_cast<const double2*>(AL + tb + 8);
+    const double2 fm23 = *reinterpret_cast<const double2*>(CP + tb + 8);
+    double e = prev;
+    e = __builtin_fma(fm01.x, dpp0_f64<DPP_ROW_SHR(1)>(e), e);
+    e = __builtin_fma(fm01.y, dpp0_f64<DPP_ROW_SHR(2)>(e), e);
+    e = __builtin_fma(fm23.x, dpp0_f64<DPP_ROW_SHR(4)>(e), e);
+    if (NKB > 1) e = __builtin_fma(fm23.y, dpp0_f64<DPP_ROW_SHR(8)>(e), e);
+    double din = dpp0_f64<DPP_ROW_SHR(1)>(e);
+    din = s_first ? 0.0 : din;
+    // ---- local backward sweep with the forward fix-up folded in
+    double nxt = 0.0;
+#pragma unroll
+    for (int mm = 6; mm >= 0; mm -= 2) {
+        const double2 tpi = tab2(PI, mm), tcp = tab2(CP, mm);
+#pragma unroll
+        for (int u = 1; u >= 0; --u) {
+            const int m = mm + u;
+            const double dp = d[m] + (u ? tpi.y : tpi.x) * din;
+            nxt = dp - (u ? tcp.y : tcp.x) * nxt;
+            d[m] = nxt;
+        }
+        if (mm == 4) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- backward carries: first_j = F_j + Q_j first_{j+1}
+    const double2 bm01 = *reinterpret_cast<const double2*>(PP + tb + 8);
+    const double2 bm23 = *reinterpret_cast<const double2*>(QQ + tb + 8);
+    double f = nxt;
+    f = __builtin_fma(bm01.x, dpp0_f64<DPP_ROW_SHL(1)>(f), f);
+    f = __builtin_fma(bm01.y, dpp0_f64<DPP_ROW_SHL(2)>(f), f);
+    f = __builtin_fma(bm23.x, dpp0_f64<DPP_ROW_SHL(4)>(f), f);
+    if (NKB > 1) f = __builtin_fma(bm23.y, dpp0_f64<DPP_ROW_SHL(8)>(f), f);
+    double sin_ = dpp0_f64<DPP_ROW_SHL(1)>(f);
+    sin_ = s_last ? 0.0 : sin_;
+    double* srow = Sp + tl * RS + kb;
+    const int sx = (seg >> 1) & 3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double2 tps = tab2(PSI, 2 * c);
+        double2 v;
+        v.x = d[2 * c] + tps.x * sin_; v.y = d[2 * c + 1] + tps.y * sin_;
+        *reinterpret_cast<double2*>(srow + 2 * (c ^ sx)) = v;
+    }
+}
+
+// VAR = false: uniform batch of 64 x 16 surfaces (BASELINE configs 2/3), surface -> workgroup mapping as surface_dense_kernel.
+// VAR = true : work list of a size class (n <= 64 * NKB strikes per surface, run-time maturity count), or a uniform
+//              batch with nK != 64.
+template <int METHOD, int NKB, bool VAR>
+__global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, VarList list) {
+    using G = PassGeom<NKB>;
+    constexpr int RP = G::RP, NPASS = G::NPASS, KCAP = G::KCAP, RS = G::RS, TN = G::TN;
+    constexpr int PFP = NKB == 1 ? NPASS : 1;        // passes per prefetch group (64 strikes: the whole surface)
+    constexpr int NPRE = PFP * RP * NKB;             // doubles per lane and group
+    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot methods only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int mT = p.mT, mK = p.mK;
+    double* Yp = reinterpret_cast<double*>(smem);
+    double* Sp = Yp + G::PLANE;
+    double* TB = Sp + G::PLANE;
+    double* Ksh = TB + (VAR ? 7 : 6) * TN;
+    const double nanv = __builtin_nan(""), inf = __builtin_inf();
+    auto nostamp = [](int) {};
+
+    TqTables tt;
+    const double* TTp = nullptr;
+    const double* Wp = nullptr;
+    tq_from_shared(p.tqs, tt, TTp, Wp);
+    const int nT = VAR ? p.nT : DT;
+
+    // spare slots that are read but never staged must hold finite numbers (they meet zero coefficients)
+    for (int i = lane; i < 2 * G::PLANE; i += 64) Yp[i] = 0.0;
+
+    const bool kq_shared = p.kq_stride == 0;
+    const bool act = lane < mK;
+    double xq = (kq_shared && act) ? p.Kq[lane] : nanv;
+
+    // ---- work distribution
+    int64_t it, it_end, it_step;
+    if (!VAR) {
+        const int R = p.map_groups;
+        const int64_t region = (p.B + R - 1) / R;
+        const int64_t base = (int64_t)(blockIdx.x % R) * region;
+        it_end = base + region < p.B ? base + region : p.B;
+        it_step = gridDim.x / R;
+        it = base + blockIdx.x / R;
+    } else {
+        it_end = list.items ? (int64_t)*list.count : p.B;
+        it_step = gridDim.x;
+        it = blockIdx.x;
+    }
+    auto at = [&](int64_t i, int& n, int64_t& koff) -> int64_t {
+        if (VAR && list.items) { const VarItem v = list.items[i]; n = v.n; koff = v.koff; return v.b; }
+        n = p.nK; koff = i * p.k_stride; return i;
+    };
+
+    // ---- prefetch registers: group g of a surface = its passes g*PFP .. g*PFP + PFP - 1
+    double pre[NPRE], pre_k[NKB];
+    auto issue_group = [&](int64_t b, int64_t ko, int nn, int g) {
+        if (!VAR) {      // chunk c of the surface = 16 B at c*1024 + lane*16: rows 2c + (lane >> 5), strikes 2(lane & 31), +1
+            const double2* s2 = reinterpret_cast<const double2*>(p.sigma + b * (int64_t)(DT * DK));
+#pragma unroll
+            for (int c = 0; c < NPRE / 2; ++c) {
+                const double2 v = s2[(g * (NPRE / 2) + c) * 64 + lane];
+                pre[2 * c] = v.x; pre[2 * c + 1] = v.y;
+            }
+        } else {
+            const double* sb = p.k_off ? p.sigma + (int64_t)nT * ko : p.sigma + b * (int64_t)nT * p.nK;
+#pragma unroll
+            for (int r = 0; r < PFP * RP; ++r)
+#pragma unroll
+                for (int blk = 0; blk < NKB; ++blk) {
+                    const int t = g * PFP * RP + r, k = blk * 64 + lane;
+                    pre[r * NKB + blk] = (t < nT && k < nn) ? sb[(int64_t)t * nn + k] : 0.0;      // rows beyond nT: zeros
+                }
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int blk = 0; blk < NKB; ++blk) {
+                const int k = blk * 64 + lane;
+                pre_k[blk] = VAR ? (k < nn ? p.K[ko + k] : inf) : p.K[b * p.k_stride + k];
+            }
+        }
+    };
+
+    int n = KCAP, n_next = KCAP;
+    int64_t koff = 0, koff_next = 0, b = 0, b_next = 0;
+    if (it < it_end) { b = at(it, n, koff); issue_group(b, koff, n, 0); }
+
+    while (it < it_end) {
+        double* outb = p.out + b * (int64_t)mT * mK;
+        const int64_t it_next = it + it_step;
+        const bool more = it_next < it_end;
+        if (more) b_next = at(it_next, n_next, koff_next);
+        if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;      // issued ahead of the next prefetch (vmcnt is in order)
+        bool ok = !tt.unsorted;
+        double z[DT];
+        int j = 0, jj = 0;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int g = ps / PFP, slot = ps % PFP;
+            __syncthreads();                                   // the previous pass's gathers are done with the planes
+            // ---- stage pass ps; any non-finite quote (NaN = missing, or an infinity) sends the surface to the generic kernel
+            double acc = 0.0;
+            if (!VAR) {
+#pragma unroll
+                for (int c = 0; c < RP / 2; ++c) {
+                    const int tl = 2 * c + (lane >> 5), k = 2 * (lane & 31);
+                    double2 v; v.x = pre[slot * RP + 2 * c]; v.y = pre[slot * RP + 2 * c + 1];
+                    *reinterpret_cast<double2*>(&Yp[tl * RS + k]) = v;
+                }
+                if (ps == 0) {
+#pragma unroll
+                    for (int c = 0; c < NPRE; ++c) acc = __builtin_fma(pre[c], 0.0, acc);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RP; ++r)
+#pragma unroll
+                    for (int blk = 0; blk < NKB; ++blk) {
+                        const double v = pre[(slot * RP + r) * NKB + blk];
+                        Yp[r * RS + blk * 64 + lane] = v;
+                        acc = __builtin_fma(v, 0.0, acc);
+                    }
+            }
+            if (ps == 0) {
+#pragma unroll
+                for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
+            }
+            if (VAR || ps == 0) ok = ok && __ballot(acc != 0.0) == 0ull;
+            if (slot == PFP - 1) {                             // the group's registers are free: request the next group
+                if (g + 1 < NPASS / PFP) issue_group(b, koff, n, g + 1);
+                else if (more) issue_group(b_next, koff_next, n_next, 0);
+            }
+            __syncthreads();
+            if (ok) {
+                if (ps == 0) {
+                    if (ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR>(Ksh, n, lane, TB);
+                    // ---- strike search + Hermite weights of this lane's output strike (once per surface)
+#pragma unroll
+                    for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
+#pragma unroll
+                    for (int st = 4; st >= 1; st >>= 1) if (Ksh[j + st] <= xq) j += st;
+                    const double xl = Ksh[n - 1];
+                    const bool left = !(Ksh[0] <= xq);
+                    jj = j > n - 2 ? n - 2 : j;
+                    const double x0 = Ksh[jj], x1 = Ksh[jj + 1];
+                    const bool okq = !left && ((xq <= xl) || d_extrap_right(METHOD));
+                    const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;
+                    w0 = okq ? (1.0 + 2.0 * t) * omt * omt : nanv;
+                    w1 = t * t * (3.0 - 2.0 * t);
+                    w2 = u * omt * omt;
+                    w3 = u * t * (t - 1.0);
+                }
+                if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR>(Yp, Sp, TB, lane);
+                __syncthreads();
+                // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
+                const int o0 = jj, o1 = jj + 1, q0 = p_swz(jj), q1 = p_swz(jj + 1);
+                if (ABL == 2 || ABL == 6) {
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) z[ps * RP + r] = Yp[r * RS + lane] + w0;
+                    continue;
+                }
+                constexpr int LA = RP < 4 ? RP - 1 : 3;
+                double g0[4], g1[4], g2[4], g3[4];
+#pragma unroll
+                for (int r = 0; r < LA; ++r) {
+                    g0[r] = Yp[r * RS + o0]; g1[r] = Yp[r * RS + o1]; g2[r] = Sp[r * RS + q0]; g3[r] = Sp[r * RS + q1];
+                }
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    if (r + LA < RP) {
+                        const int nn = r + LA;
+                        g0[nn & 3] = Yp[nn * RS + o0]; g1[nn & 3] = Yp[nn * RS + o1];
+                        g2[nn & 3] = Sp[nn * RS + q0]; g3[nn & 3] = Sp[nn * RS + q1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    z[ps * RP + r] = w0 * g0[r & 3] + w1 * g1[r & 3] + w2 * g2[r & 3] + w3 * g3[r & 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (ok) {
+            if (act) dense_maturity_pass<METHOD, true, false, VAR, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp, 0, 0, nT);
+            if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
+        } else if (lane == 0) {
+            reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;     // redone by the generic kernel (second launch)
+        }
+        it = it_next; b = b_next; n = n_next; koff = koff_next;
+    }
+}
+
+// Dispatch of the row-pass kernels.  Returns 1 if dispatched (pass kernel(s) + filtered generic redo pass), 0 if the
+// call is outside their scope (see the head of this file), -1 on a launch error.
+inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name) {
+    SurfaceParams p = p_in;
+    hipStream_t st = cx.st;
+    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) return 0;
+    if (p.t_stride != 0 || p.tq_stride != 0) return 0;
+    if (p.mK > 64 || p.mT > D_MAX_MT) return 0;
+    if (p.nT < 4 || p.nT > DT || p.nK < 4 || p.nK > 128) return 0;
+    if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
+    if (p.k_off && p.B > 0x7fffffffLL) return 0;
+    const bool fixed64 = !p.k_off && p.nK == DK && p.nT == DT && !(reinterpret_cast<uintptr_t>(p.sigma) & 15);
+    TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
+    if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
+    p.tqs = tq;
+    auto grid_for = [&](size_t lds, int64_t work) {
+        int per_cu = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));     // LDS is granted in 1280-byte granules
+        per_cu = per_cu > 12 ? 12 : (per_cu < 1 ? 1 : per_cu);                 // 3 wavefronts per SIMD (168 VGPRs)
+#ifdef IVS_PASS_PER_CU
+        per_cu = IVS_PASS_PER_CU;                                              // diagnostic builds (tools/pass_api.hip)
+#endif
+        const int64_t g = (int64_t)cx.num_cu * per_cu;
+        return g > work ? work : g;
+    };
+    const VarList none{nullptr, nullptr};
+    if (fixed64) {
+        const size_t lds = pass_lds_bytes<1, false>();
+        const int64_t grid = grid_for(lds, p.B);
+        p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);
+        if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, false>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
+#ifndef IVS_DIAG_MINIMAL
+        else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, false>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
+#endif
+        *name = p.method == IVS_CUBIC ? "surface_pass_kernel<cubic>" : "surface_pass_kernel<cubicspline>";
+    } else {
+#ifdef IVS_DIAG_MINIMAL
+        return 0;
+#else
+        VarItem* lists = nullptr;
+        int32_t* counts = nullptr;
+        if (p.k_off) {      // classify once into one work list per size class (workspace: counters, then B items per class)
+            counts = reinterpret_cast<int32_t*>(cx.ws + WS_TQ_BYTES);
+            lists = reinterpret_cast<VarItem*>(cx.ws + WS_TQ_BYTES + WS_COUNTS_BYTES);
+            if (hipMemsetAsync(counts, 0, WS_COUNTS_BYTES, st) != hipSuccess) return -1;
+            int64_t cb = (p.B + 1023) / 1024;
+            const int64_t cap = (int64_t)cx.num_cu * 8;
+            if (cb > cap) cb = cap;
+            hipLaunchKernelGGL(var_classify_kernel, dim3((unsigned)cb), dim3(256), 0, st, p, lists, lists + p.B, counts);
+        }
+        const VarList wl1{lists, counts}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr};
+        const bool need1 = p.k_off ? true : p.nK <= 64, need2 = p.nK > 64;
+        if (need1) {
+            const size_t lds = pass_lds_bytes<1, true>();
+            const int64_t grid = grid_for(lds, p.B);
+            if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);
+            else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);
+        }
+        if (need2) {
+            const size_t lds = pass_lds_bytes<2, true>();
+            const int64_t grid = grid_for(lds, p.B);
+            if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 2, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl2);
+            else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 2, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl2);
+        }
+        *name = p.method == IVS_CUBIC ? "surface_pass_var_kernel<cubic>" : "surface_pass_var_kernel<cubicspline>";
+#endif
+    }
+    if (hipGetLastError() != hipSuccess) return -1;
+    launch_surface_generic<true>(p, cx);     // redo pass for tagged surfaces (cheap when none are)
+    return 1;
+}
+
+}  // namespace ivs

@@ -37,14 +37,47 @@ def _f64(torch, t, name):
     return t.contiguous()
 
 
+_ragged_ok = {}      # (data_ptr, numel, version) of k_off tensors already validated against K / sigma / nK_max
+
+
+def _check_ragged(torch, K, sigma, k_off, nK, nT):
+    """Reject CSR offsets the kernels cannot serve BEFORE anything is launched (one small device reduction + one
+    D2H read per distinct k_off tensor; the result is cached on the tensor's identity and version counter)."""
+    key = (k_off.data_ptr(), k_off.numel(), k_off._version, K.numel(), sigma.numel(), nK, nT)
+    if _ragged_ok.get("key") == key:
+        return
+    if k_off.numel() < 1:
+        raise ValueError("k_off must hold B+1 offsets")
+    span = k_off[1:] - k_off[:-1]
+    stats = torch.stack([k_off[0], k_off[-1], span.min() if span.numel() else k_off[0] * 0,
+                         span.max() if span.numel() else k_off[0] * 0]).tolist()
+    first, last, smin, smax = (int(v) for v in stats)
+    if first != 0 or smin < 0:
+        raise ValueError("k_off must start at 0 and be non-decreasing")
+    if smax > nK:
+        raise ValueError(f"k_off: a surface has {smax} strikes but nK_max={nK}")
+    if K.numel() != last or sigma.numel() != nT * last:
+        raise ValueError(f"ragged batch: K has {K.numel()} and sigma {sigma.numel()} entries, k_off[-1]={last}, nT={nT}")
+    _ragged_ok["key"] = key
+
+
+def surface_workspace(B: int, ragged: bool, device=None):
+    """Device scratch for one surface_batch call (ivs_surface_workspace_bytes): uint8 CUDA tensor, 256-byte aligned."""
+    torch = require_device()
+    n = _lib.load().ivs_surface_workspace_bytes(int(B), 1 if ragged else 0)
+    return torch.empty(n, dtype=torch.uint8, device=device or "cuda")
+
+
 def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: Optional[int] = None,
                   n_maturities: Optional[int] = None, out=None, status=None, stream=None,
-                  force_generic: bool = False):
+                  force_generic: bool = False, workspace=None, map_groups: int = 0):
     """Interpolate a batch of (strike x maturity) surfaces on the current device.
 
     Uniform: K [B,nK] or [nK] (shared), sigma [B,nT,nK].  Ragged: K flat [total], sigma flat
     [nT*total] (surface b row-major [nT][nK_b]), k_off int64 [B+1], nK_max, n_maturities.
     T [nT] or [B,nT]; Kq [mK] or [B,mK]; Tq [mT] or [B,mT].  Returns (out [B,mT,mK], status [B]).
+    `workspace`: uint8 CUDA tensor from surface_workspace() (allocated per call when omitted; pass one to keep the
+    call allocation-free, e.g. under hipGraph capture).
     """
     torch = require_device()
     lib = _lib.load()
@@ -61,7 +94,9 @@ def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: O
             raise TypeError("k_off must be a CUDA int64 tensor")
         if nK_max is None or n_maturities is None:
             raise ValueError("ragged batches need nK_max and n_maturities")
+        k_off = k_off.contiguous()
         B = k_off.numel() - 1; nT = int(n_maturities); nK = int(nK_max); k_stride = 0
+        _check_ragged(torch, K, sigma, k_off, nK, nT)
     if T.shape[-1] != nT or (T.dim() == 2 and T.shape[0] != B):
         raise ValueError("T shape does not match sigma")
     t_stride = 0 if T.dim() == 1 else nT
@@ -74,9 +109,16 @@ def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: O
         out = torch.empty((B, mT, mK), dtype=torch.float64, device=sigma.device)
     if status is None:
         status = torch.empty((B,), dtype=torch.int32, device=sigma.device)
+    need = lib.ivs_surface_workspace_bytes(B, 0 if k_off is None else 1)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=sigma.device)
+    elif workspace.numel() * workspace.element_size() < need or not workspace.is_cuda:
+        raise ValueError(f"workspace too small: {workspace.numel() * workspace.element_size()} < {need} bytes")
+    flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | _lib.flag_map_groups(map_groups)
     rc = lib.ivs_surface_batch_f64(_ptr(K), _ptr(k_off), k_stride, nK, _ptr(T), t_stride, nT, _ptr(sigma), B,
                                    _ptr(Kq), kq_stride, mK, _ptr(Tq), tq_stride, mT, _ptr(out), _ptr(status),
-                                   code, _lib.FLAG_FORCE_GENERIC if force_generic else 0, _stream(torch, stream))
+                                   code, flags, _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                   _stream(torch, stream))
     _lib.check(rc, "ivs_surface_batch_f64")
     return out, status
 
