@@ -539,13 +539,15 @@ struct TqTables {
 struct TqShared {
     double TT[DT * 4];                    // per maturity knot: {PP, QQ, AL, CP} | {r0, r1, r2, -} | {T_j, T_j+1, 1/dt, dt}
     double W[D_MAX_MT * 4];               // per query row: Hermite weights | {Tq, T_j, T_j+1, 1/dt}
-    double CP[DT];                        // CP_i once more, contiguous: the backward sweep re-requests it (two s_load_dwordx16)
-                                          // instead of keeping the forward sweep's copies alive in 32 SGPRs
+    double CP[DT];                        // the not-a-knot tables once more as separate arrays: the register solve requests
+    double PP[DT], QQ[DT], AL[DT];        // eight rows of a coefficient with ONE s_load_dwordx16 (three requests in flight, one
+                                          // wait per half) instead of waiting for a scalar load in every row
     double pm_last;
     unsigned long long iv_lo, iv_hi;
     int n_left, n_hold, n_nan, unsorted;
 };
-static_assert(offsetof(TqShared, W) == DT * 4 * 8 && offsetof(TqShared, CP) == (DT * 4 + D_MAX_MT * 4) * 8, "TT, W, CP back to back");
+static_assert(offsetof(TqShared, W) == DT * 4 * 8 && offsetof(TqShared, CP) == (DT * 4 + D_MAX_MT * 4) * 8 &&
+              offsetof(TqShared, AL) == (DT * 4 + D_MAX_MT * 4 + 3 * DT) * 8, "TT, W, CP, PP, QQ, AL back to back");
 #define IVS_CONST __attribute__((address_space(4)))
 typedef const double IVS_CONST* cdptr;
 __device__ __forceinline__ cdptr to_const(const double* p) { return (cdptr)p; }
@@ -645,47 +647,6 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
     __syncthreads();
 }
 
-// One wavefront per call: the T-phase of a batch whose T and Tq are shared, published as TqShared (see there).
-template <int METHOD, bool NTR>
-__global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared* o) {
-    __shared__ __attribute__((aligned(16))) double sm[8 * 72 + 64 + 64];
-    const int lane = threadIdx.x;
-    double* scratch = sm;                  // NTR: factor_tables_var scratch
-    double* Tsh = sm + 8 * 72;
-    double* TT = Tsh + 64;
-    TqTables tt;
-    dense_t_phase<METHOD, false, NTR>(p.T, p.Tq, p.mT, lane, Tsh, TT, nullptr, tt, p.nT, scratch);
-    if (lane < DT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o->TT[lane * 4 + c] = TT[lane * 4 + c];
-        o->CP[lane] = TT[lane * 4 + 3];
-    }
-    if (lane < p.mT) { o->W[lane * 4] = tt.w0; o->W[lane * 4 + 1] = tt.w1; o->W[lane * 4 + 2] = tt.w2; o->W[lane * 4 + 3] = tt.w3; }
-    if (lane == 0) {
-        o->pm_last = tt.pm_last; o->iv_lo = tt.iv_lo; o->iv_hi = tt.iv_hi;
-        o->n_left = tt.n_left; o->n_hold = tt.n_hold; o->n_nan = tt.n_nan; o->unsorted = tt.unsorted;
-    }
-}
-template <bool NTR>
-inline void launch_tq_tables(const SurfaceParams& p, TqShared* o, hipStream_t st) {
-#define IVS_TQ_CASE(M) case M: hipLaunchKernelGGL((tq_tables_kernel<M, NTR>), dim3(1), dim3(64), 0, st, p, o); break;
-    switch (p.method) {
-        IVS_TQ_CASE(IVS_LINEAR) IVS_TQ_CASE(IVS_CUBIC) IVS_TQ_CASE(IVS_CUBICSPLINE) IVS_TQ_CASE(IVS_SLINEAR)
-        IVS_TQ_CASE(IVS_PCHIP) IVS_TQ_CASE(IVS_AKIMA)
-        default: break;
-    }
-#undef IVS_TQ_CASE
-}
-// fills the uniform part of TqTables from the published tables (scalar loads)
-__device__ __forceinline__ void tq_from_shared(const void* tqs, TqTables& tt, const double*& TT, const double*& W) {
-    const TqShared* g = static_cast<const TqShared*>(tqs);
-    const TqShared IVS_CONST* c = (const TqShared IVS_CONST*)g;
-    tt.w0 = tt.w1 = tt.w2 = tt.w3 = 0.0;
-    tt.pm_last = c->pm_last; tt.iv_lo = c->iv_lo; tt.iv_hi = c->iv_hi;
-    tt.n_left = c->n_left; tt.n_hold = c->n_hold; tt.n_nan = c->n_nan; tt.unsorted = c->unsorted;
-    TT = g->TT; W = g->W;
-}
-
 // Maturity direction for one block of 64 output strikes (q-lane): z[t] = strike-pass value of row t at the lane's
 // strike.  Solves the lane's 16-knot system in registers (cubic) and walks the output rows class by class
 // (left-NaN rows, rows per maturity interval, hold rows, right-NaN rows), storing 512-B rows through a
@@ -704,9 +665,15 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
     constexpr bool w_lds = WLDS && !SM;
     const double nanv = __builtin_nan("");
     const cdptr cTT = to_const(TT), cW = to_const(W);          // SM only
-    const cdptr cCP = to_const(TT + DT * 4 + D_MAX_MT * 4);    // TqShared::CP (TT, W, CP are laid out back to back)
+    const cdptr cCP = to_const(TT + DT * 4 + D_MAX_MT * 4);    // TqShared::CP, PP, QQ, AL (laid out back to back behind TT, W)
+    const cdptr cPP = cCP + DT, cQQ = cCP + 2 * DT, cAL = cCP + 3 * DT;
     // ---- maturity direction (q-lane, registers).  Row pointers are wave-uniform (scalar base),
     // the lane contributes only its 32-bit column offset.
+    // the packed per-interval row counts stay packed: made opaque here, their extraction (one s_bfe per interval) cannot be
+    // hoisted out of the caller's surface loop as 15 separate scalars (which were spilled to VGPR lanes and read back)
+    unsigned long long ivl = tt.iv_lo, ivh = tt.iv_hi;
+    asm volatile("" : "+s"(ivl), "+s"(ivh));
+    auto n_iv = [&](int j) { return (int)(((j < 8 ? ivl : ivh) >> (8 * (j & 7))) & 0xffull); };
     int tq = 0;
     double* rp = outb + q0;                                    // row tq of the output block: uniform running pointer
     cdptr wp = cW;                                             // SM: weights of row tq
@@ -768,28 +735,39 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         } else if (ABL == 3 || ABL == 6) {
 #pragma unroll
             for (int i = 0; i < DT; ++i) s[i] = z[i] * 0.5;
-        } else if (SM) {   // forward / backward sweep with the table rows in SGPRs (scalar loads, grouped 4 rows at a time)
+        } else if (SM) {   // forward / backward sweep with the table rows in SGPRs: SMG rows per request group
+            constexpr int SMG = 4;
 #pragma unroll
-            for (int i = 0; i < DT; ++i) {
-                const double pp = cTT[i * 4], qq = cTT[i * 4 + 1], al = cTT[i * 4 + 2];
-                if (!NTR) {
-                    const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
-                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
-                    prev = (pp * dA + qq * dB) - al * prev;
-                } else {
-                    const int ia = i == 0 ? 0 : i - 1, ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
-                    const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
-                    double r = pp * dA + qq * dB;
-                    if (i >= 3) r += ((i == nT - 1) ? pm_last : 0.0) * (z[i - 1] - z[i - 2]);     // scalar select
-                    prev = r - al * prev;
+            for (int h = 0; h < DT / SMG; ++h) {
+                double pp[SMG], qq[SMG], al[SMG];
+#pragma unroll
+                for (int u = 0; u < SMG; ++u) { pp[u] = cPP[SMG * h + u]; qq[u] = cQQ[SMG * h + u]; al[u] = cAL[SMG * h + u]; }
+#pragma unroll
+                for (int u = 0; u < SMG; ++u) {
+                    const int i = SMG * h + u;
+                    if (!NTR) {
+                        const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                        const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                        prev = (pp[u] * dA + qq[u] * dB) - al[u] * prev;
+                    } else {
+                        const int ia = i == 0 ? 0 : i - 1, ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
+                        const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
+                        double r = pp[u] * dA + qq[u] * dB;
+                        if (i >= 3) r += ((i == nT - 1) ? pm_last : 0.0) * (z[i - 1] - z[i - 2]);     // scalar select
+                        prev = r - al[u] * prev;
+                    }
+                    s[i] = prev;
                 }
-                s[i] = prev;
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = DT - 2; i >= 0; --i) {
-                s[i] = s[i] - cCP[i] * s[i + 1];              // CP = 0 from the last row on
-                if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            for (int h = 1; h >= 0; --h) {
+                double cp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cp[u] = cCP[8 * h + u];
+#pragma unroll
+                for (int u = 7; u >= 0; --u) { const int i = 8 * h + u; if (i <= DT - 2) s[i] = s[i] - cp[u] * s[i + 1]; }   // CP = 0 from the last row on
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {   // forward sweep; table rows (broadcast b128 pairs) are loaded 4 steps ahead
             constexpr int LA = 4;
@@ -832,7 +810,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
         stamp(4);
 #pragma unroll
         for (int jv = 0; jv < DT - 1; ++jv) {
-            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, adv()) {
+            for (int c = 0, n = n_iv(jv); c < n; ++c, adv()) {
                 if (!mine(tq)) continue;
                 double a0, a1, a2, a3;
                 weights(tq, a0, a1, a2, a3);
@@ -846,7 +824,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
 #pragma clang fp contract(off)
                 // many query rows per interval (mT > 16): np.interp's slope of the interval once per lane, two
                 // operations per output row (same arithmetic as lerp_fast, hence the same bits)
-                const int n = tt.n_iv(jv);
+                const int n = n_iv(jv);
                 if (n == 0) continue;
                 double2 tj, tr;                                                             // {T_j, T_j+1}, {1/dt, dt}
                 if (SM) { tj = double2{cTT[jv * 4], cTT[jv * 4 + 1]}; tr = double2{cTT[jv * 4 + 2], cTT[jv * 4 + 3]}; }
@@ -870,7 +848,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                 }
                 continue;
             }
-            for (int c = 0, n = tt.n_iv(jv); c < n; ++c, adv()) {
+            for (int c = 0, n = n_iv(jv); c < n; ++c, adv()) {
                 if (!mine(tq)) continue;
                 double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
                 weights(tq, xt, t0, t1, rdt);
@@ -894,6 +872,47 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
     }
     for (int c = 0; c < tt.n_hold; ++c, adv()) if (mine(tq)) put(tq, z_last);
     for (int c = 0; c < tt.n_nan; ++c, adv()) if (mine(tq)) put(tq, nanv);
+}
+
+// One wavefront per call: the T-phase of a batch whose T and Tq are shared, published as TqShared (see there).
+template <int METHOD, bool NTR>
+__global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared* o) {
+    __shared__ __attribute__((aligned(16))) double sm[8 * 72 + 64 + 64];
+    const int lane = threadIdx.x;
+    double* scratch = sm;                  // NTR: factor_tables_var scratch
+    double* Tsh = sm + 8 * 72;
+    double* TT = Tsh + 64;
+    TqTables tt;
+    dense_t_phase<METHOD, false, NTR>(p.T, p.Tq, p.mT, lane, Tsh, TT, nullptr, tt, p.nT, scratch);
+    if (lane < DT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o->TT[lane * 4 + c] = TT[lane * 4 + c];
+        o->CP[lane] = TT[lane * 4 + 3]; o->PP[lane] = TT[lane * 4]; o->QQ[lane] = TT[lane * 4 + 1]; o->AL[lane] = TT[lane * 4 + 2];
+    }
+    if (lane < p.mT) { o->W[lane * 4] = tt.w0; o->W[lane * 4 + 1] = tt.w1; o->W[lane * 4 + 2] = tt.w2; o->W[lane * 4 + 3] = tt.w3; }
+    if (lane == 0) {
+        o->pm_last = tt.pm_last; o->iv_lo = tt.iv_lo; o->iv_hi = tt.iv_hi;
+        o->n_left = tt.n_left; o->n_hold = tt.n_hold; o->n_nan = tt.n_nan; o->unsorted = tt.unsorted;
+    }
+}
+template <bool NTR>
+inline void launch_tq_tables(const SurfaceParams& p, TqShared* o, hipStream_t st) {
+#define IVS_TQ_CASE(M) case M: hipLaunchKernelGGL((tq_tables_kernel<M, NTR>), dim3(1), dim3(64), 0, st, p, o); break;
+    switch (p.method) {
+        IVS_TQ_CASE(IVS_LINEAR) IVS_TQ_CASE(IVS_CUBIC) IVS_TQ_CASE(IVS_CUBICSPLINE) IVS_TQ_CASE(IVS_SLINEAR)
+        IVS_TQ_CASE(IVS_PCHIP) IVS_TQ_CASE(IVS_AKIMA)
+        default: break;
+    }
+#undef IVS_TQ_CASE
+}
+// fills the uniform part of TqTables from the published tables (scalar loads)
+__device__ __forceinline__ void tq_from_shared(const void* tqs, TqTables& tt, const double*& TT, const double*& W) {
+    const TqShared* g = static_cast<const TqShared*>(tqs);
+    const TqShared IVS_CONST* c = (const TqShared IVS_CONST*)g;
+    tt.w0 = tt.w1 = tt.w2 = tt.w3 = 0.0;
+    tt.pm_last = c->pm_last; tt.iv_lo = c->iv_lo; tt.iv_hi = c->iv_hi;
+    tt.n_left = c->n_left; tt.n_hold = c->n_hold; tt.n_nan = c->n_nan; tt.unsorted = c->unsorted;
+    TT = g->TT; W = g->W;
 }
 
 template <int METHOD, bool TSHARED, bool WLDS, bool STAMP = false>
