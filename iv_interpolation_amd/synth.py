@@ -87,12 +87,22 @@ def torch_batch(B: int, nK: int = 64, nT: int = 16, seed: int = BASE_SEED, devic
     return {"K": K, "T": T, "sigma": sig}
 
 
-def torch_ragged_batch(B: int, nT: int = 16, lo: int = 8, hi: int = 128, seed: int = BASE_SEED, device="cuda"):
-    """Config 5 in HBM: counts ~ randint(lo, hi+1); strikes/vols from the same formulas (flat CSR)."""
+def ragged_counts(B: int, lo: int = 8, hi: int = 128, seed: int = BASE_SEED):
+    """Strike counts of a config-5 batch (host, deterministic in `seed`): every rank of a sharded run draws the SAME
+    counts for the global batch and then builds only its own shard (torch_ragged_batch(nk=counts[lo:hi]))."""
+    return np.random.default_rng(seed).integers(lo, hi + 1, B).astype(np.int64)
+
+
+def torch_ragged_batch(B: int, nT: int = 16, lo: int = 8, hi: int = 128, seed: int = BASE_SEED, device="cuda", nk=None):
+    """Config 5 in HBM: counts ~ randint(lo, hi+1) (or the given `nk`); strikes/vols from the same formulas (flat CSR)."""
     import torch
     g = torch.Generator(device=device); g.manual_seed(seed)
     f64 = dict(dtype=torch.float64, device=device)
-    nk = torch.randint(lo, hi + 1, (B,), generator=g, device=device, dtype=torch.int64)
+    if nk is None:
+        nk = torch.randint(lo, hi + 1, (B,), generator=g, device=device, dtype=torch.int64)
+    else:
+        nk = torch.as_tensor(np.asarray(nk, np.int64), device=device)
+        B = int(nk.numel())
     k_off = torch.zeros(B + 1, dtype=torch.int64, device=device); k_off[1:] = torch.cumsum(nk, 0)
     total = int(k_off[-1])
     sid = torch.repeat_interleave(torch.arange(B, device=device), nk)           # surface of each strike

@@ -34,6 +34,24 @@ def test_ragged_bounds_balance_bytes():
         assert max(loads) - min(loads) <= 2 * 128
 
 
+def test_strong_scaling_shards_of_one_global_batch():
+    """bench.py --scaling strong: every rank draws the SAME strike counts for the global ragged batch and takes the
+    block ragged_shard_bounds gives it; the blocks tile the batch and carry equal strike totals (uniform batches:
+    shard_bounds, sizes within one surface of each other)."""
+    B = 100_003
+    counts = synth.ragged_counts(B, 8, 128, seed=synth.BASE_SEED + 1000)
+    assert np.array_equal(counts, synth.ragged_counts(B, 8, 128, seed=synth.BASE_SEED + 1000))      # deterministic
+    assert counts.min() >= 8 and counts.max() <= 128
+    k_off = np.concatenate([[0], np.cumsum(counts)])
+    for world in (2, 4, 8):
+        b = sharding.ragged_shard_bounds(k_off, world)
+        assert b[0][0] == 0 and b[-1][1] == B and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        loads = [int(k_off[hi] - k_off[lo]) for lo, hi in b]
+        assert max(loads) - min(loads) <= 2 * 128 and sum(loads) == int(k_off[-1])
+        u = [sharding.shard_bounds(B, r, world) for r in range(world)]
+        assert sum(hi - lo for lo, hi in u) == B
+
+
 def _worker(rank, world, port, q):
     import ivs_oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
