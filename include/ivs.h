@@ -41,9 +41,13 @@ enum {
     IVS_PCHIP       = 6, /* 'pchip': PchipInterpolator; NaN left, extrapolates right; >= 2 knots */
     IVS_AKIMA       = 7, /* 'akima': Akima1DInterpolator; NaN outside the hull; >= 3 knots (scipy's 2-knot case is undefined) */
     IVS_FROM_DERIVATIVES = 8, /* 'from_derivatives' / 'piecewise_polynomial': BPoly on values = Bernstein-form lines; NaN outside; >= 2 */
-    IVS_QUADRATIC   = 9  /* 'quadratic': interp1d(kind=2) = make_interp_spline(k=2), knots at the midpoints of the sites; NaN outside; >= 3 */
+    IVS_QUADRATIC   = 9, /* 'quadratic': interp1d(kind=2) = make_interp_spline(k=2), knots at the midpoints of the sites; NaN outside; >= 3 */
+    IVS_BARYCENTRIC = 10,/* 'barycentric': scipy barycentric_interpolate, ONE polynomial through all valid knots; NaN left of the
+                            first knot, the polynomial continues on the right; 1..IVS_POLY_MAX_KNOTS knots; 1-D kernels only */
+    IVS_KROGH       = 11 /* 'krogh': scipy krogh_interpolate, the same polynomial in Newton form (divided differences); 1-D only */
 };
-/* methods 0-3, 6, 7 run on the dense fast kernels; 4, 5, 8, 9 on the generic surface kernel; all on the 1-D kernels */
+#define IVS_POLY_MAX_KNOTS 32   /* above this the reference's own polynomial is numerical noise: IVS_ST_ILL_CONDITIONED */
+/* methods 0-3, 6, 7 run on the dense fast kernels; 4, 5, 8, 9 on the generic surface kernel; 0-11 on the 1-D kernels */
 
 /* return codes */
 enum {
@@ -58,7 +62,8 @@ enum {
 enum {
     IVS_ST_OK            = 0,
     IVS_ST_TOO_FEW_KNOTS = 1, /* the reference's scipy call raises here -> interpolate_symbol returns None */
-    IVS_ST_BAD_SHAPE     = 2  /* ragged surface whose k_off span is negative or exceeds nK: skipped, outputs untouched */
+    IVS_ST_BAD_SHAPE     = 2, /* ragged surface whose k_off span is negative or exceeds nK: skipped, outputs untouched */
+    IVS_ST_ILL_CONDITIONED = 4 /* 'barycentric' / 'krogh' with more than IVS_POLY_MAX_KNOTS valid knots: values are NaN */
 };
 
 int         ivs_version(void);        /* IVS_ABI_VERSION of the loaded library */

@@ -12,7 +12,7 @@ import os
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libivs.so")
 
 LINEAR, CUBIC, CUBICSPLINE, SLINEAR = 0, 1, 2, 3
-ST_OK, ST_TOO_FEW_KNOTS, ST_BAD_SHAPE = 0, 1, 2
+ST_OK, ST_TOO_FEW_KNOTS, ST_BAD_SHAPE, ST_ILL_CONDITIONED = 0, 1, 2, 4
 FLAG_FORCE_GENERIC = 1
 
 
@@ -25,10 +25,13 @@ ABI_VERSION = 2
 # pandas method names (reference core.py:61 forwards self.method) -> engine codes
 NEAREST, ZERO, PCHIP, AKIMA, FROM_DERIVATIVES = 4, 5, 6, 7, 8
 QUADRATIC = 9
+BARYCENTRIC, KROGH = 10, 11
+POLY_MAX_KNOTS = 32
 METHOD_CODES = {"linear": LINEAR, "index": LINEAR, "values": LINEAR,
                 "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
                 "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
-                "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES, "quadratic": QUADRATIC}
+                "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES, "quadratic": QUADRATIC,
+                "barycentric": BARYCENTRIC, "krogh": KROGH}
 
 
 class EngineUnavailable(RuntimeError):

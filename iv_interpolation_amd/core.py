@@ -22,7 +22,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import pandas as pd
 
-from ._lib import METHOD_CODES, ST_OK, EngineUnavailable
+from ._lib import METHOD_CODES, POLY_MAX_KNOTS, ST_ILL_CONDITIONED, ST_OK, EngineUnavailable
 
 logger = logging.getLogger("interpolation.core")   # the reference's logger name (core.py:7)
 
@@ -36,6 +36,28 @@ MINUTE_NS = 60_000_000_000
 _PANDAS_METHODS = ["linear", "time", "index", "values", "nearest", "zero", "slinear", "quadratic", "cubic",
                    "barycentric", "krogh", "spline", "polynomial", "from_derivatives", "piecewise_polynomial",
                    "pchip", "akima", "cubicspline"]
+
+
+def _chan_kind(col: pd.Series) -> str:
+    """How pandas' Series.interpolate treats a numeric channel of this dtype (reference core.py:61; verified against the
+    real reference, golden cases t1/t2/t3): 'obj' = object dtype: interpolate is a (deprecated) no-op, the column keeps
+    its source cells; 'f32' = float32: computed in float64 from the upcast knots, stored as float32; 'ext' = nullable
+    Float64 / Float32: result keeps the extension dtype; 'f64' = everything else (float64, ints: existing rules)."""
+    dt = col.dtype
+    if dt == object:
+        return "obj"
+    if isinstance(dt, pd.api.extensions.ExtensionDtype):
+        return "ext" if str(dt) in ("Float64", "Float32") else "f64"
+    return "f32" if dt == np.float32 else "f64"
+
+
+def _chan_finish(values: np.ndarray, kind: str, dtype):
+    """float64 result column -> the dtype the reference returns for this channel."""
+    if kind == "f32":
+        return values.astype(np.float32)
+    if kind == "ext":
+        return pd.array(values.astype(np.float32 if str(dtype) == "Float32" else np.float64), dtype=str(dtype))
+    return values
 
 
 class HipBackend:
@@ -56,7 +78,7 @@ class HipBackend:
 
 
 class _Prepared:
-    __slots__ = ("df", "timeline", "pos", "rowlat", "M", "chan_src", "chan_needs", "fill_cols",
+    __slots__ = ("df", "timeline", "pos", "rowlat", "M", "chan_src", "chan_needs", "chan_kind", "fill_cols",
                  "fill_valid", "src_np", "int_dtype")
 
 
@@ -129,7 +151,8 @@ class IVInterpolator:
         and one device round trip, instead of one DataFrame per symbol (batch_processor.py:67-142 loops over symbols,
         then ``iterrows()`` :166-173).  The result equals
         ``pd.concat([interpolate_symbol(g) for _, g in data.groupby("symbol", sort=True)], ignore_index=True)``
-        (symbols whose result is ``None`` contribute nothing).  Rows with a null symbol or an unparsable date are ignored."""
+        (symbols whose result is ``None`` contribute nothing; ties between duplicate timestamps are ordered like the
+        reference's ``sort_values('date')``).  Rows with a null symbol or an unparsable date are ignored."""
         for c in ["date"] + REQUIRED:
             if c not in data.columns:
                 raise KeyError(c)
@@ -137,6 +160,12 @@ class IVInterpolator:
             raise ValueError(f"method '{self.method}' is not implemented by the MI355X engine")
         code = METHOD_CODES[self.method]
         be = self._backend or HipBackend()
+        if data["date"].dtype == object:
+            # string dates: the reference sorts them LEXICOGRAPHICALLY before parsing (core.py:32-33); that order is a
+            # per-symbol property of the strings, so these frames take the per-symbol bookkeeping (one device round trip)
+            parts = [r for r in self.interpolate_batch([g for _, g in data.groupby("symbol", sort=True)]) if r is not None]
+            if parts:
+                return pd.concat(parts, ignore_index=True)
         cols_in = [c for c in data.columns if c != "date"]
         out_cols = ["date"] + cols_in + (["is_interpolated"] if "is_interpolated" not in cols_in else [])
         d_idx = pd.DatetimeIndex(pd.to_datetime(data["date"]))
@@ -147,6 +176,18 @@ class IVInterpolator:
         rows = np.flatnonzero(ok_row)
         rows = rows[np.lexsort((d_ns[rows], sym_codes[rows]))]          # by symbol, then date (stable)
         sc = sym_codes[rows]; dn = d_ns[rows]
+        tie = (sc[1:] == sc[:-1]) & (dn[1:] == dn[:-1])
+        if tie.any():
+            # duplicate timestamps inside a symbol: the reference orders a symbol's rows with sort_values('date'), i.e.
+            # numpy's quicksort on the datetime64 values (pandas nargsort; NOT the int64 view, whose vectorised sort
+            # leaves other tie orders) -- not stable beyond 16 rows -- and the tie order decides which duplicate lands on
+            # which merged-frame position (R7).  Same routine on the same values in the same input order.
+            d64 = d_ns.view("datetime64[ns]")
+            for s_id in np.unique(sc[1:][tie]):
+                lo_ = int(np.searchsorted(sc, s_id, side="left")); hi_ = int(np.searchsorted(sc, s_id, side="right"))
+                grp = np.sort(rows[lo_:hi_])                             # the symbol's rows in input order
+                rows[lo_:hi_] = grp[np.argsort(d64[grp], kind="quicksort")]
+            dn = d_ns[rows]
         S_all = len(sym_uniques)
         empty = pd.DataFrame({c: pd.Series(dtype=(bool if c == "is_interpolated" else data[c].dtype if c in data.columns else "float64"))
                               for c in out_cols})
@@ -186,9 +227,14 @@ class IVInterpolator:
         total_q = int(q_off[-1])
         src_rows = rows[ridx]                                            # positions in `data` of the on-lattice rows
         # ---- channels
-        chan = [data[c].to_numpy(dtype=np.float64, na_value=np.nan)[src_rows] for c in NUMERIC_COLS]
+        kinds = [_chan_kind(data[c]) for c in NUMERIC_COLS]
+        chan = [np.zeros(len(src_rows)) if k == "obj" else data[c].to_numpy(dtype=np.float64, na_value=np.nan)[src_rows]
+                for c, k in zip(NUMERIC_COLS, kinds)]
         nan_cnt = np.stack([np.add.reduceat(np.isnan(v).astype(np.int64), src_off[:-1]) for v in chan], 1) + (M - q)[:, None]
         needs = (nan_cnt > 0) & (nan_cnt < M[:, None])                   # pandas leaves all-NaN / no-NaN columns alone
+        for ci, k in enumerate(kinds):
+            if k == "obj":
+                needs[:, ci] = False                                     # object dtype: Series.interpolate is a no-op
         out, status = be.interp1d_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code)
         sym_ok = ~((status != ST_OK) & needs).any(1)                     # scipy would raise -> that symbol is None
         # ---- forward-fill gather index
@@ -220,14 +266,19 @@ class IVInterpolator:
             int_dtype = v.dtype if v.dtype.kind in "iub" else None
             if name in NUMERIC_COLS:
                 ci = NUMERIC_COLS.index(name)
+                if kinds[ci] == "obj":
+                    merged = np.full(total_q, np.nan, dtype=object)
+                    merged[gpos] = v
+                    cols[name] = merged
+                    continue
                 merged = np.full(total_q, np.nan)
                 merged[gpos] = chan[ci]
                 fill = np.isnan(merged) & needs[sym_of_row, ci]
                 merged = np.where(fill, out[ci], merged)
                 if nothing_missing and int_dtype is not None:
                     merged = merged.astype(int_dtype)
-                elif data[name].dtype == object:
-                    merged = merged.astype(object)
+                else:
+                    merged = _chan_finish(merged, kinds[ci], data[name].dtype)
                 cols[name] = merged
             elif name in fill_cols:
                 cols[name] = _gather(v, fidx[fill_cols.index(name)].astype(np.int64), int_dtype, nothing_missing)
@@ -305,8 +356,13 @@ class IVInterpolator:
             v = df[c].to_numpy()
             p.int_dtype[c] = v.dtype if v.dtype.kind in "iub" else None
             p.src_np[c] = v[rows_on]
-        p.chan_src, p.chan_needs = [], []
+        p.chan_src, p.chan_needs, p.chan_kind = [], [], []
         for c in NUMERIC_COLS:                                           # core.py:58-61
+            kind = _chan_kind(df[c])
+            p.chan_kind.append(kind)
+            if kind == "obj":                                            # object dtype: Series.interpolate leaves it alone
+                p.chan_src.append(np.zeros(q)); p.chan_needs.append(False)
+                continue
             v = df[c].to_numpy(dtype=np.float64, na_value=np.nan)[rows_on]
             p.chan_src.append(v)
             nn = int(np.isnan(v).sum()) + (M - q)                        # NaNs of the merged column
@@ -319,6 +375,11 @@ class IVInterpolator:
         df, M = p.df, p.M
         q = len(p.pos)
         for c in range(len(NUMERIC_COLS)):
+            if p.chan_needs[c] and status[c] == ST_ILL_CONDITIONED:
+                # documented deviation: the reference returns the (numerically meaningless) values of a polynomial of
+                # degree > POLY_MAX_KNOTS - 1; the engine does not reproduce noise and gives the symbol up
+                raise ValueError(f"method '{self.method}': one polynomial through more than {POLY_MAX_KNOTS} knots of "
+                                 f"'{NUMERIC_COLS[c]}' is ill-conditioned; not computed")
             if p.chan_needs[c] and status[c] != ST_OK:
                 # scipy raises inside Series.interpolate (too few knots) -> core.py:83-85
                 raise ValueError("The number of derivatives at boundaries does not match: "
@@ -332,14 +393,19 @@ class IVInterpolator:
                 continue
             if name in NUMERIC_COLS:
                 ci = NUMERIC_COLS.index(name)
+                if p.chan_kind[ci] == "obj":                             # untouched by interpolate: source cells only
+                    merged = np.full(M, np.nan, dtype=object)
+                    merged[p.pos] = p.src_np[name]
+                    cols[name] = merged
+                    continue
                 merged = np.full(M, np.nan)
                 merged[p.pos] = p.chan_src[ci]
                 if p.chan_needs[ci]:
                     merged = np.where(np.isnan(merged), out[ci], merged)
                 if nothing_missing and p.int_dtype[name] is not None:    # nothing missing: int column stays int
                     merged = merged.astype(p.int_dtype[name])
-                elif df[name].dtype == object:                           # object-typed numeric column keeps its dtype
-                    merged = merged.astype(object)
+                else:
+                    merged = _chan_finish(merged, p.chan_kind[ci], df[name].dtype)
                 cols[name] = merged
             elif name in p.fill_cols:
                 fi = p.fill_cols.index(name)

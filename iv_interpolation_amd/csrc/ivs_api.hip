@@ -40,7 +40,7 @@ int check_launch(const char* what) {
     return IVS_OK;
 }
 
-bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_QUADRATIC; }
+bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_KROGH; }
 
 // CU count of the CURRENT device, cached per device index (a process may drive several devices)
 std::atomic<int> g_cu[ivs::IVS_MAX_DEV];
@@ -260,6 +260,7 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
     g_err[0] = 0;
     g_last_kernel = "";
     if (!valid_method(method)) return fail(IVS_EINVAL, "ivs_surface_batch_f64: unknown method %d", method);
+    if (ivs::method_is_poly(method)) return fail(IVS_EINVAL, "ivs_surface_batch_f64: method %d ('barycentric' / 'krogh') is 1-D only", method);
     if (B < 0 || nK < 0 || nT < 0 || mK < 0 || mT < 0) return fail(IVS_EINVAL, "ivs_surface_batch_f64: negative size");
     if (B == 0 || mK == 0 || mT == 0) return IVS_OK;
     if (!K || !T || !sigma || !Kq || !Tq || !out) return fail(IVS_EINVAL, "ivs_surface_batch_f64: null pointer");

@@ -167,11 +167,13 @@ __host__ __device__ __forceinline__ bool method_is_cubic(int m) {
     return m == IVS_CUBIC || m == IVS_CUBICSPLINE || m == IVS_PCHIP || m == IVS_AKIMA || m == IVS_QUADRATIC;
 }
 __device__ __forceinline__ bool method_extrapolates_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }
+// one polynomial through all knots: the per-knot table holds barycentric weights / Newton coefficients
+__host__ __device__ __forceinline__ bool method_is_poly(int m) { return m == IVS_BARYCENTRIC || m == IVS_KROGH; }
 __device__ __forceinline__ int method_min_knots(int m) {
     switch (m) {
         case IVS_LINEAR: return 0;
         case IVS_CUBIC: return 4;
-        case IVS_NEAREST: case IVS_ZERO: return 1;
+        case IVS_NEAREST: case IVS_ZERO: case IVS_BARYCENTRIC: case IVS_KROGH: return 1;
         case IVS_AKIMA: return 3;
         case IVS_QUADRATIC: return 3;
         default: return 2;
@@ -310,6 +312,52 @@ __device__ __forceinline__ double eval_quadratic(const XA& x, const SA& c, int n
     return h0 * c(ell - 2) + h1 * c(ell - 1) + h2 * c(ell);
 }
 
+// ---- 'barycentric' / 'krogh' (oracle barycentric_weights / barycentric_eval / krogh_coeffs / krogh_eval; scipy _polyint.py)
+// weight of knot j: 1 / prod_{k != j} (c (x_j - x_k)), c = 4 / (x_max - x_min); factors in index order
+template <class XA>
+__device__ __forceinline__ double barycentric_weight(const XA& x, int n, int j) {
+    if (n == 1) return 1.0;
+    const double cap = 4.0 / (x(n - 1) - x(0));
+    const double xj = x(j);
+    double prod = 1.0;
+    for (int k = 0; k < n; ++k) prod *= (k == j) ? 1.0 : cap * (xj - x(k));
+    return 1.0 / prod;
+}
+template <class XA, class YA, class WA>
+__device__ __forceinline__ double eval_barycentric(const XA& x, const YA& y, const WA& w, int n, double xq) {
+    if (!(xq >= x(0))) return qnan();                          // pandas keeps NaN left of the first knot
+    double num = 0.0, den = 0.0, hit = 0.0;
+    bool on_node = false;
+    for (int k = 0; k < n; ++k) {
+        const double c = xq - x(k);
+        if (c == 0.0) { on_node = true; hit = y(k); break; }
+        const double t = w(k) / c;
+        num += t * y(k); den += t;
+    }
+    return on_node ? hit : num / den;
+}
+// Newton coefficients by scipy's recurrence (one thread; n <= IVS_POLY_MAX_KNOTS); vk = scratch of n entries
+template <class XA, class YA, class CW, class VW>
+__device__ __forceinline__ void krogh_coeffs(const XA& x, const YA& y, CW& c, VW& vk, int n) {
+    c.set(0, y(0));
+    for (int k = 1; k < n; ++k) {
+        vk.set(0, y(k));
+        for (int i = 0; i < k; ++i) vk.set(i + 1, (c(i) - vk(i)) / (x(i) - x(k)));
+        c.set(k, vk(k));
+    }
+}
+template <class XA, class CA>
+__device__ __forceinline__ double eval_krogh(const XA& x, const CA& c, int n, double xq) {
+#pragma clang fp contract(off)
+    if (!(xq >= x(0))) return qnan();
+    double pi = 1.0, p = c(0);
+    for (int k = 1; k < n; ++k) {
+        pi = (xq - x(k - 1)) * pi;
+        p = p + pi * c(k);
+    }
+    return p;
+}
+
 // knot slopes of the method's interpolant (needs n >= method_min_knots and n >= 2)
 template <class XA, class YA, class SW, class CW>
 __device__ __forceinline__ void method_slopes(int method, const XA& x, const YA& y, SW& s, CW& scratch, int n) {
@@ -329,6 +377,8 @@ __device__ __forceinline__ double eval_method(int method, const XA& x, const YA&
         case IVS_ZERO: return eval_zero(x, y, n, j, xq);
         case IVS_FROM_DERIVATIVES: return eval_bpoly_linear(x, y, n, j, xq);
         case IVS_QUADRATIC: return eval_quadratic(x, s, n, j, xq);
+        case IVS_BARYCENTRIC: return eval_barycentric(x, y, s, n, xq);
+        case IVS_KROGH: return eval_krogh(x, s, n, xq);
         default: return eval_cubic(x, y, s, n, j, xq, method_extrapolates_right(method));
     }
 }

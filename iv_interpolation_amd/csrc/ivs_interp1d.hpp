@@ -56,10 +56,29 @@ __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p)
     }
     const int minkn = method_min_knots(p.method);
     const bool solve = method_is_cubic(p.method) && base >= minkn && base >= 2;      // block-uniform
+    const bool poly = method_is_poly(p.method);
+    const bool poly_ok = poly && base >= 1 && base <= IVS_POLY_MAX_KNOTS;
     double* gs = p.ws + (int64_t)c * p.total_knots + a;
     if (tid == 0) {
-        p.wn[sc] = (int32_t)base;
-        p.status[sc] = (base > 0 && base < minkn) ? IVS_ST_TOO_FEW_KNOTS : IVS_ST_OK;
+        // a polynomial through more than IVS_POLY_MAX_KNOTS knots: the eval kernel sees 0 knots (all NaN) and the status
+        // tells the host that the reference's (numerically meaningless) values are not reproduced
+        p.wn[sc] = (poly && base > IVS_POLY_MAX_KNOTS) ? 0 : (int32_t)base;
+        p.status[sc] = (base > 0 && base < minkn) ? IVS_ST_TOO_FEW_KNOTS
+                     : ((poly && base > IVS_POLY_MAX_KNOTS) ? IVS_ST_ILL_CONDITIONED : IVS_ST_OK);
+    }
+    if (poly_ok) {      // per-knot table: barycentric weights (one thread per knot) or Newton coefficients (one thread)
+        __syncthreads();                                       // the compacted knots of this block are visible
+        for (int i = tid; i < (int)base; i += 256) { px[i] = wx[i]; py[i] = wy[i]; }
+        __syncthreads();
+        CView xv{px, 1}, yv{py, 1};
+        if (p.method == IVS_BARYCENTRIC) {
+            if (tid < (int)base) gs[tid] = barycentric_weight(xv, (int)base, tid);
+        } else {
+            if (tid == 0) { View cv{ps, 1}, vv{pc, 1}; krogh_coeffs(xv, yv, cv, vv, (int)base); }
+            __syncthreads();
+            if (tid < (int)base) gs[tid] = ps[tid];
+        }
+        return;
     }
     if (solve && base <= P1_STAGE) {
         // the serial recurrence reads its knots from LDS (one global round trip per step would dominate)
@@ -122,7 +141,7 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
         xq[u] = !active[u] ? qnan() : (p.xq ? p.xq[g] : (double)(g - p.q_off[s]));
     }
     const int method = p.method;
-    const bool cubic = method_is_cubic(method);
+    const bool cubic = method_is_cubic(method) || method_is_poly(method);      // a per-knot table rides along with (x, y)
     const bool lerp_method = method == IVS_LINEAR || method == IVS_SLINEAR;
     const int minkn = method_min_knots(method);
     for (int c = 0; c < p.C; ++c) {

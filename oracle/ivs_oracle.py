@@ -51,8 +51,16 @@ FROM_DERIVATIVES = 8   # pandas 'from_derivatives' / 'piecewise_polynomial' (BPo
 QUADRATIC = 9    # pandas 'quadratic'  (interp1d kind=2 -> make_interp_spline(k=2): quadratic B-spline with knots at the
                  #                       midpoints of the data sites, NaN outside hull, >= 3 knots)
 
+BARYCENTRIC = 10  # pandas 'barycentric' (scipy barycentric_interpolate: ONE polynomial through all valid knots;
+                  #                       leading NaN kept, trailing NaN extrapolated by the polynomial, >= 1 knot)
+KROGH = 11        # pandas 'krogh'       (scipy krogh_interpolate: the same polynomial in Newton form)
+POLY_MAX_KNOTS = 32   # beyond this the interpolating polynomial on an (almost) equispaced grid is numerical noise in
+                      # the reference itself (scipy's two routes disagree at 1e-8 of the curve's scale at 32 knots, and
+                      # its barycentric weights even change from run to run: random node permutation); the engine
+                      # reports ST_ILL_CONDITIONED there and the symbol becomes None (documented deviation)
+
 METHOD_CODES = {
-    "linear": LINEAR, "index": LINEAR, "values": LINEAR, "quadratic": QUADRATIC,
+    "linear": LINEAR, "index": LINEAR, "values": LINEAR, "quadratic": QUADRATIC, "barycentric": BARYCENTRIC, "krogh": KROGH,
     "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
     "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
     "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES,
@@ -61,12 +69,13 @@ METHOD_CODES = {
 # status codes shared with include/ivs.h
 ST_OK = 0
 ST_TOO_FEW_KNOTS = 1   # the reference raises inside scipy -> interpolate_symbol returns None
+ST_ILL_CONDITIONED = 4 # 'barycentric' / 'krogh' with more than POLY_MAX_KNOTS valid knots
 
 
 def min_knots(method: int) -> int:
     """Fewest valid knots the reference accepts before scipy raises."""
     return {LINEAR: 0, CUBIC: 4, CUBICSPLINE: 2, SLINEAR: 2, NEAREST: 1, ZERO: 1, PCHIP: 2, AKIMA: 3,
-            FROM_DERIVATIVES: 2, QUADRATIC: 3}[method]
+            FROM_DERIVATIVES: 2, QUADRATIC: 3, BARYCENTRIC: 1, KROGH: 1}[method]
 
 
 # --------------------------------------------------------------------------- linear
@@ -384,6 +393,70 @@ def quadratic_eval(xv, yv, c, xq):
 
 
 # --------------------------------------------------------------------------- 1-D operator
+# --------------------------------------------------------------------------- one polynomial through all knots
+def barycentric_weights(xv):
+    """scipy/interpolate/_polyint.py BarycentricInterpolator.__init__: w_j = 1 / prod_{k != j} (c (x_j - x_k)) with the
+    capacity scaling c = 4 / (max - min).  scipy multiplies the factors in a RANDOM order (rng.permutation, unseeded):
+    here in index order -- the reference's own values move in the last digits from run to run."""
+    n = xv.size
+    if n == 1:
+        return np.ones(1)
+    cap = 4.0 / (xv.max() - xv.min())
+    w = np.empty(n)
+    for j in range(n):
+        d = cap * (xv[j] - xv)
+        d[j] = 1.0
+        w[j] = 1.0 / np.prod(d)
+    return w
+
+
+def barycentric_eval(xv, yv, xq):
+    """BarycentricInterpolator._evaluate (second barycentric form; a query on a node returns that node's value).
+    pandas' forward fill direction keeps NaN left of the first knot and fills everything to its right (the
+    polynomial extrapolates)."""
+    w = barycentric_weights(xv)
+    out = np.full(xq.shape, np.nan)
+    for i, x in enumerate(xq):
+        if not (x >= xv[0]):
+            continue
+        c = x - xv
+        hit = np.flatnonzero(c == 0)
+        if hit.size:
+            out[i] = yv[hit[0]]
+            continue
+        c = w / c
+        out[i] = np.dot(c, yv) / np.sum(c)
+    return out
+
+
+def krogh_coeffs(xv, yv):
+    """scipy KroghInterpolator (distinct nodes): divided differences by the recurrence of _polyint.py."""
+    n = xv.size
+    c = np.zeros(n); c[0] = yv[0]
+    Vk = np.zeros(n)
+    for k in range(1, n):
+        Vk[0] = yv[k]
+        for i in range(k):
+            Vk[i + 1] = (c[i] - Vk[i]) / (xv[i] - xv[k])
+        c[k] = Vk[k]
+    return c
+
+
+def krogh_eval(xv, yv, xq):
+    """KroghInterpolator._evaluate: p = c_0 + sum_k c_k prod_{i<k} (x - x_i)."""
+    c = krogh_coeffs(xv, yv)
+    out = np.full(xq.shape, np.nan)
+    for i, x in enumerate(xq):
+        if not (x >= xv[0]):
+            continue
+        pi = 1.0; p = c[0]
+        for k in range(1, xv.size):
+            pi = (x - xv[k - 1]) * pi
+            p = p + pi * c[k]
+        out[i] = p
+    return out
+
+
 def interp1d(xk, yk, xq, method: int):
     """One masked-knot 1-D interpolation (one channel of core.py:58-61, generalised to
     real-valued knot/query coordinates).  NaN in ``yk`` = missing quote (not a knot).
@@ -401,6 +474,10 @@ def interp1d(xk, yk, xq, method: int):
         return np.full(xq.shape, np.nan), ST_OK
     if n < min_knots(method):
         return np.full(xq.shape, np.nan), ST_TOO_FEW_KNOTS
+    if method in (BARYCENTRIC, KROGH):
+        if n > POLY_MAX_KNOTS:
+            return np.full(xq.shape, np.nan), ST_ILL_CONDITIONED
+        return (barycentric_eval if method == BARYCENTRIC else krogh_eval)(xv, yv, xq), ST_OK
     if method == LINEAR:
         return lerp_eval(xv, yv, xq, right_hold=True), ST_OK
     if method == SLINEAR:

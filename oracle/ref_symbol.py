@@ -57,14 +57,22 @@ def interpolate_symbol(symbol_data: pd.DataFrame, method: str = "linear",
         pos = np.arange(m, dtype=np.float64)                            # RangeIndex positions (R8)
         for col in NUMERIC_COLS:                                        # :58-61
             if col in merged.columns:
-                y = merged[col].to_numpy(np.float64)
+                dt = merged[col].dtype
+                if dt == object:
+                    continue                                            # Series.interpolate on object dtype: (deprecated) no-op
+                y = merged[col].to_numpy(np.float64, na_value=np.nan)
                 if np.isnan(y).all() or not np.isnan(y).any():
                     continue                                            # missing.py:468-472
                 val, st = O.interp1d(pos, y, pos, code)
                 if st != O.ST_OK:
                     return None                                         # scipy raises -> :83-85
                 y = np.where(np.isnan(y), val, y)
-                merged[col] = y
+                if str(dt) in ("Float64", "Float32"):                   # nullable floats keep their dtype
+                    merged[col] = pd.array(y.astype(np.float32 if str(dt) == "Float32" else np.float64), dtype=str(dt))
+                elif dt == np.float32:                                  # computed in float64, stored back as float32
+                    merged[col] = y.astype(np.float32)
+                else:
+                    merged[col] = y
         for col in FILL_COLS:                                           # :64-68
             if col in merged.columns:
                 merged[col] = merged[col].ffill()

@@ -190,6 +190,43 @@ for m in ("quadratic",):
     add(f"x9_chan_one_knot_{m}", dfc, m, 2)
 
 
+# appended in round 2 (after every earlier block, so that the earlier vectors stay byte-identical):
+# dtype of a numeric channel -- pandas leaves an object column alone (Series.interpolate on object dtype is a deprecated
+# no-op: only the source rows survive the dropna), computes a float32 column in float64 and stores float32, keeps the
+# nullable Float64 dtype
+for m in ("linear", "cubic"):
+    dft = frame(12, 1); dft["iv"] = dft["iv"].astype(object)
+    add(f"t1_object_iv_{m}", dft, m)
+    dft = frame(12, 1); dft["iv"] = dft["iv"].astype(np.float32); dft.loc[3, "iv"] = np.nan
+    add(f"t2_float32_iv_{m}", dft, m)
+    dft = frame(12, 1); dft["iv"] = dft["iv"].astype("Float64"); dft.loc[4, "iv"] = pd.NA
+    add(f"t3_Float64_iv_{m}", dft, m)
+dft = frame(12, 1); dft["underlying_price"] = dft["underlying_price"].astype(object); dft["time_to_maturity"] = dft["time_to_maturity"].astype(np.float32)
+add("t1_object_underlying_float32_ttm", dft)
+# duplicate timestamps in a symbol with MORE than 16 rows: sort_values('date') is numpy's quicksort (introsort), which is
+# not stable beyond 16 elements -- the tie order of the duplicates (hence which value sits at which merged-frame
+# position) is whatever that routine leaves
+for k_, (n_, m) in enumerate([(24, "linear"), (24, "cubic"), (40, "linear"), (33, "cubicspline")]):
+    dft = frame(n_, 700 + k_)
+    for i in (5, 11, 12, 20):
+        dft.loc[i, "date"] = dft.loc[i - 1, "date"]
+    if k_ % 2:
+        dft = dft.sample(frac=1.0, random_state=70 + k_).reset_index(drop=True)
+    add(f"t4_dup_gt16_{n_}_{m}", dft, m, 2)
+# polynomial interpolation through ALL knots ('barycentric', 'krogh': scipy barycentric_interpolate / krogh_interpolate).
+# scipy's barycentric weights use a random permutation of the nodes (results move in the last digits from run to run);
+# with more than ~30 knots the polynomial itself is numerical noise.  Pinned for small knot counts.
+for m in ("barycentric", "krogh"):
+    add(f"y1_{m}", frame(12, 1), m)
+    dfx = frame(14, 5)
+    dfx.loc[4:6, "iv"] = np.nan; dfx.loc[0:1, "underlying_price"] = np.nan; dfx.loc[12:13, "time_to_maturity"] = np.nan
+    add(f"y5_nan_{m}", dfx, m)
+    add(f"y8_16to64_{m}", lattice_frame(p16, 81), m, 2)
+    for n in (1, 2, 3, 5):
+        add(f"y9_few{n}_{m}", lattice_frame(np.arange(max(n, 2)) * 20, 99 + n) if n > 1 else lattice_frame(np.arange(2) * 20, 100).assign(iv=[0.5, np.nan]), m, 2)
+    add(f"y9_n24_{m}", lattice_frame(np.arange(24) * 9, 124), m, 2)
+
+
 def enc(col: pd.Series):
     """Encode a column without pickling: returns dict of arrays + dtype tag."""
     dt = str(col.dtype)
@@ -198,6 +235,8 @@ def enc(col: pd.Series):
         if getattr(col.dt, "tz", None) is not None:
             v = col.dt.tz_convert("UTC").dt.tz_localize(None)
         return {"v": v.astype("datetime64[ns]").astype("int64").to_numpy()}, dt
+    if dt == "Float64":                      # nullable extension dtype: values + mask
+        return {"v": col.to_numpy(np.float64, na_value=np.nan), "null": col.isna().to_numpy()}, "Float64"
     if col.dtype == object:
         null = col.isna().to_numpy()
         isstr = np.array([isinstance(x, str) for x in col], bool)

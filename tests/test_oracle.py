@@ -9,7 +9,7 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import ivs_oracle as O          # noqa: E402
 import ref_symbol               # noqa: E402
-from golden_io import GOLDEN, SymbolCases, assert_symbol_frame   # noqa: E402
+from golden_io import GOLDEN, SymbolCases, assert_symbol_frame, method_tolerances   # noqa: E402
 
 CASES = SymbolCases()
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
@@ -24,8 +24,7 @@ RTOL, ATOL = 1e-12, 1e-13
 def test_symbol_contract(name):
     c = CASES.cases[name]
     got = ref_symbol.interpolate_symbol(CASES.input(name), c["method"], c["min_points"])
-    lin = c["method"] in ("linear", "index", "values", "nearest", "zero", "from_derivatives", "piecewise_polynomial")
-    assert_symbol_frame(got, CASES.expected(name), rtol=0 if lin else RTOL, atol=0 if lin else ATOL, name=name)
+    assert_symbol_frame(got, CASES.expected(name), name=name, **method_tolerances(c["method"]))
 
 
 def test_real1d_against_pandas_vectors():
