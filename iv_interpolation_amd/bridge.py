@@ -159,6 +159,46 @@ class InterpolatedToOHLCVConverter:
         return ohlcv_df.sort_values("timestamp")
 
     # ------------------------------------------------------------------ store-facing wrappers
+    def get_interpolated_symbols(self, batch_id: Optional[int] = None) -> List[str]:
+        """ohlcv_converter.py:31-55 against the frame store: symbols with interpolated rows (of that batch), sorted."""
+        try:
+            symbols = list(self.db_manager.symbols("interpolated_trading_tickers"))
+            if batch_id:
+                kept = []
+                for sym in symbols:
+                    df = self.db_manager.read_output(sym)
+                    if df is not None and "batch_id" in df.columns and (df["batch_id"] == batch_id).any():
+                        kept.append(sym)
+                symbols = kept
+            logger.info(f"Found {len(symbols)} symbols with interpolated data")
+            return sorted(symbols)
+        except Exception as e:
+            logger.error(f"Failed to retrieve interpolated symbols: {e}")
+            return []
+
+    def convert_batch(self, symbols: Optional[List[str]] = None, batch_id: Optional[int] = None) -> Dict:
+        """ohlcv_converter.py:463-493: the same tally dictionary; symbols are converted in order on ONE generator stream."""
+        if symbols is None:
+            symbols = self.get_interpolated_symbols(batch_id)
+        if not symbols:
+            logger.warning("No symbols found for OHLCV conversion")
+            return {"total": 0, "success": 0, "errors": 0, "skipped": 0}
+        logger.info(f"Converting {len(symbols)} symbols to OHLCV format")
+        results = {"total": len(symbols), "success": 0, "errors": 0, "skipped": 0}
+        for symbol in symbols:
+            r = self.convert_symbol_to_ohlcv(symbol, batch_id)
+            if r["status"] == "success":
+                results["success"] += 1
+                logger.info(f"{symbol}: {r['input_points']} -> {r['output_candles']} candles")
+            elif r["status"] == "skipped":
+                results["skipped"] += 1
+                logger.warning(f"{symbol}: {r['reason']}")
+            else:
+                results["errors"] += 1
+                logger.error(f"{symbol}: {r['error']}")
+        logger.info(f"OHLCV conversion complete: {results['success']} success, {results['errors']} errors, {results['skipped']} skipped")
+        return results
+
     def convert_symbol_to_ohlcv(self, symbol: str, batch_id: Optional[int] = None) -> Dict:
         """ohlcv_converter.py:57-136 against a frame store (``db_manager`` = iv_interpolation_amd.frame_store.FrameStore)
         instead of PostgreSQL: same result dictionaries."""

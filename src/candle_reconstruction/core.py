@@ -5,4 +5,4 @@ import sys
 _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
-from iv_interpolation_amd.candles import CandleReconstructor  # noqa: E402,F401
+from iv_interpolation_amd.candles import CandleReconstructor, MultiSymbolCandleReconstructor  # noqa: E402,F401

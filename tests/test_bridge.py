@@ -156,6 +156,27 @@ def test_converter_import_path_selection_quality_and_stream_state():
     assert c._generate_ohlcv_from_interpolated(pd.DataFrame({"symbol": ["s"], "timestamp": ["2024-01-01"], "iv": [0.5]})) is None
 
 
+def test_convert_batch_and_symbol_listing_on_the_frame_store(tmp_path):
+    """ohlcv_converter.py:31-55 and :463-493 (reference main.py:400 calls convert_batch): frame-store backed, one
+    generator stream over the symbols in order, the reference's tally dictionary."""
+    from oracle_backend import OracleBridgeBackend
+    from iv_interpolation_amd.bridge import InterpolatedToOHLCVConverter
+    from iv_interpolation_amd.frame_store import FrameStore, synthetic_symbol
+    store = FrameStore(str(tmp_path))
+    for i, (sym, batch) in enumerate((("aaa", 7), ("bbb", 7), ("ccc", 8))):
+        f = synthetic_symbol(sym, 6, seed=i); f["is_interpolated"] = False
+        store.write_output(sym, f, batch)
+    store.write_output("empty", synthetic_symbol("empty", 6, seed=9).iloc[:0], 7)
+    c = InterpolatedToOHLCVConverter(store, _config("simple_spread"), backend=OracleBridgeBackend(), seed=5)
+    assert c.get_interpolated_symbols() == ["aaa", "bbb", "ccc", "empty"]
+    assert c.get_interpolated_symbols(batch_id=7) == ["aaa", "bbb"]
+    tally = c.convert_batch(batch_id=7)
+    assert tally == {"total": 2, "success": 2, "errors": 0, "skipped": 0}
+    assert store.symbols("minute_candles") == ["aaa", "bbb"] and len(store.read_table("minute_candles", "aaa")) == 6
+    assert c.convert_batch(symbols=["empty", "nope"]) == {"total": 2, "success": 0, "errors": 0, "skipped": 2}
+    assert c.convert_batch(symbols=[]) == {"total": 0, "success": 0, "errors": 0, "skipped": 0}
+
+
 # ---------------------------------------------------------------- GPU
 def _dev(a):
     import torch

@@ -70,3 +70,74 @@ def test_hip_candles_batch_vs_oracle():
         assert np.array_equal(o["timestamp"].to_numpy().astype("datetime64[ns]").astype(np.int64), ref["timestamp"])
         for k in KEYS:
             assert np.array_equal(o[k].to_numpy(), ref[k], equal_nan=True)
+
+
+# ---- host-side API of the reference's module kept by the drop-in (core.py:108-300); expectations below were read off
+# the REAL reference run on the same frames (known answers, data only)
+def _kat_frame():
+    ts = pd.date_range("2023-03-01 09:00", periods=12, freq="1min")
+    o = 100 + np.arange(12.0)
+    return pd.DataFrame({"symbol": "s", "timestamp": ts, "open": o, "high": o + 2, "low": o - 1, "close": o + 1,
+                         "volume": np.arange(12.0)})
+
+
+def test_validate_and_stats_known_answers():
+    from oracle_backend import OracleCandleBackend
+    from iv_interpolation_amd.candles import CandleReconstructor
+    df = _kat_frame()
+    r = CandleReconstructor("5min", backend=OracleCandleBackend())
+    assert r.validate_candle_data(df) is True
+    assert r.validate_candle_data(df.assign(high=df.low - 1)) is False          # high < low
+    assert r.validate_candle_data(df.assign(volume=-1.0)) is False              # negative volume
+    assert r.validate_candle_data(df.assign(open=np.nan)) is False              # nulls in a critical column
+    assert r.validate_candle_data(df.iloc[:0]) is False
+    assert r.validate_candle_data(df.drop(columns=["high"])) is False           # any exception -> False
+    out = r.reconstruct_symbol_candles(df)
+    st = r.get_reconstruction_stats(df, out)
+    assert st["original_candles"] == 12 and st["reconstructed_candles"] == 2 and st["compression_ratio"] == 6.0
+    assert st["original_timespan"] == pd.Timedelta(minutes=11) and st["reconstructed_timespan"] == pd.Timedelta(minutes=5)
+    assert st["coverage_ratio"] == pytest.approx(0.45454545454545453, abs=0)
+    assert st["total_volume_original"] == 66.0 and st["total_volume_reconstructed"] == 45.0
+    assert st["volume_preservation"] == pytest.approx(0.31818181818181823, abs=1e-16)
+    assert r.get_reconstruction_stats(df.iloc[:0], out) == {} and r.get_reconstruction_stats(df, out.iloc[:0]) == {}
+
+
+def test_symbol_column_rules_like_the_reference_agg():
+    from oracle_backend import OracleCandleBackend
+    from iv_interpolation_amd.candles import CandleReconstructor
+    df = _kat_frame()
+    r = CandleReconstructor("5min", backend=OracleCandleBackend())
+    assert r.reconstruct_symbol_candles(df.drop(columns=["symbol"])) is None   # agg({'symbol': 'first'}) raises -> None
+    d2 = df.copy(); d2["symbol"] = [None, "a", "a", "a", "a", "b", "b", None, "b", "b", "c", "c"]
+    out = r.reconstruct_symbol_candles(d2)
+    assert list(out["symbol"]) == ["a", "b"] and list(out["open"]) == [100.0, 105.0] and list(out["volume"]) == [10.0, 35.0]
+    bad = df.copy(); bad["open"] = "not a number"
+    assert r.reconstruct_symbol_candles(bad) is None                             # documented: non-numeric OHLCV -> None
+
+
+def test_multi_symbol_reconstructor_on_the_frame_store(tmp_path):
+    from types import SimpleNamespace
+    from oracle_backend import OracleCandleBackend
+    from iv_interpolation_amd.candles import MultiSymbolCandleReconstructor
+    from iv_interpolation_amd.frame_store import FrameStore
+    from candle_reconstruction.core import MultiSymbolCandleReconstructor as Shim      # reference main.py:28 import path
+    assert Shim is MultiSymbolCandleReconstructor
+    store = FrameStore(str(tmp_path))
+    good = _kat_frame(); good["symbol"] = "good"
+    short = _kat_frame().iloc[:3].copy(); short["symbol"] = "short"
+    broken = _kat_frame(); broken["symbol"] = "broken"; broken["high"] = broken["low"] - 5
+    for name, f in (("good", good), ("short", short), ("broken", broken)):
+        store.write_table("minute_candles", name, f)
+    cfg = SimpleNamespace(candle_reconstruction=SimpleNamespace(target_frequency="5min"))
+    m = MultiSymbolCandleReconstructor(store, cfg, backend=OracleCandleBackend())
+    assert m.get_symbols_with_minute_data() == ["broken", "good", "short"]
+    assert m.get_symbols_with_minute_data("2030-01-01", "2030-01-02") == []
+    res = {r["symbol"]: r for r in m.process_symbols(["good", "short", "broken", "missing"])}
+    assert res["good"]["status"] == "success" and res["good"]["input_candles"] == 12 and res["good"]["output_candles"] == 2
+    assert res["good"]["stats"]["compression_ratio"] == 6.0
+    assert res["short"] == {"symbol": "short", "status": "skipped", "reason": "Reconstruction failed"}
+    assert res["broken"] == {"symbol": "broken", "status": "error", "error": "Invalid input candle data"}
+    assert res["missing"] == {"symbol": "missing", "status": "skipped", "reason": "No minute data found"}
+    assert m.process_symbol("good")["status"] == "success"                         # upsert: still two rows afterwards
+    saved = store.read_table("reconstructed_candles", "good")
+    assert len(saved) == 2 and list(saved["open"]) == [100.0, 105.0]
