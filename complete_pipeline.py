@@ -40,8 +40,11 @@ class CompleteOptimizedPipeline:
         self.seed = int.from_bytes(os.urandom(4), "little") if seed is None else int(seed)
         self._rng_pos, self._rng_tail = 0, (0, 0)
         # the reference builds IVInterpolator() with defaults here (:49); config values are honoured instead
+        # ... including `preserve_greeks` (reference config.py:46, read by nothing there): the interpolated rows then carry
+        # the delta..rho columns the reference's schema reserves for them (src/database/schema.py:36-40)
         self.iv_interpolator = IVInterpolator(method=config.interpolation.method,
-                                              min_points=config.interpolation.min_data_points, backend=backend)
+                                              min_points=config.interpolation.min_data_points, backend=backend,
+                                              preserve_greeks=bool(getattr(config.interpolation, "preserve_greeks", False)))
         self.interrupted = False
 
     def setup_database_tables(self) -> dict:

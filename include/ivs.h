@@ -91,6 +91,29 @@ int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same call with the Black-Scholes Greeks as an EPILOGUE (reference config.py:46 `preserve_greeks`: "Recalculate Greeks
+ * after interpolation"; columns delta, gamma, theta, vega, rho of src/database/schema.py:36-40; formulas
+ * src/interpolation/greeks.py:12-43).  The reference never wires the flag up; here the eval kernel forms the five values
+ * of an output row from the channel values it has just produced (a row that is a knot of a channel uses the source cell,
+ * as the reference's frame does) plus the forward-filled strike / interest_rate / callput of that row:
+ *   ch_iv, ch_underlying, ch_ttm     channel numbers of sigma, S and T inside yk
+ *   fill_idx [rows][fill_stride]     output of ivs_ffill_index_batch for this batch (same q_off); row_strike / row_rate /
+ *                                    row_callput = its row for that column, or -1 when the frame has no such column
+ *                                    (no strike: NaN Greeks; no interest_rate: 0.0, the schema default; no callput: call)
+ *   strike_src, rate_src [total_src] source-row values of those columns; is_put_src: 0 call, 1 put, 2 null (-> NaN Greeks)
+ *   greeks [5][greeks_stride]        delta, gamma, theta (per day), vega and rho (per 1 %), put rho unsigned like the reference
+ */
+int ivs_interp1d_greeks_batch_f64(const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
+                                  int64_t n_series, int32_t n_channels, int64_t total_knots,
+                                  const double* xq, const int64_t* q_off, int64_t total_queries,
+                                  double* out, int64_t out_stride, int32_t* status, int32_t method,
+                                  int32_t ch_iv, int32_t ch_underlying, int32_t ch_ttm,
+                                  const int32_t* fill_idx, int64_t fill_stride, int32_t row_strike, int32_t row_rate,
+                                  int32_t row_callput, const double* strike_src, const double* rate_src,
+                                  const uint8_t* is_put_src, double* greeks, int64_t greeks_stride,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Forward-fill gather index: the "index of the last valid source row at or before
  * output row i" of core.py:64-68 (nine `fillna(method='ffill')` columns), for S symbols.
  *

@@ -54,6 +54,9 @@ SIGNATURES = {
     "ivs_interp1d_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "ivs_interp1d_batch_f64": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _i64, _p, _p, _i64, _p, _i64, _p, _i32,
                                          _p, _sz, _p]),
+    "ivs_interp1d_greeks_batch_f64": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _i64, _p, _p, _i64, _p, _i64, _p, _i32,
+                                                _i32, _i32, _i32, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64,
+                                                _p, _sz, _p]),
     "ivs_ffill_index_batch": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _i64, _p, _i64, _p]),
     "ivs_bs_greeks_f64": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "ivs_candle_aggregate_f64": (C.c_int, [_p] * 7 + [_i64, _i64, _i64] + [_p] * 8),

@@ -31,6 +31,7 @@ FILL_COLS = ["symbol", "strike", "callput", "interest_rate", "mark_price",      
              "index_price", "volume", "quote_volume", "record_time"]
 REQUIRED = ["symbol", "iv", "underlying_price", "time_to_maturity"]                 # core.py:74
 MINUTE_NS = 60_000_000_000
+GREEK_COLS = ["delta", "gamma", "theta", "vega", "rho"]                              # schema.py:36-40
 
 # pandas accepts these names; the ones not in METHOD_CODES are not implemented by the engine yet
 _PANDAS_METHODS = ["linear", "time", "index", "values", "nearest", "zero", "slinear", "quadratic", "cubic",
@@ -76,6 +77,47 @@ class HipBackend:
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
         return engine.ffill_index_batch(d(src_pos), d(src_off), d(valid), d(q_off), int(total_q)).cpu().numpy()
 
+    def interp1d_greeks_batch(self, xk, yk, knot_off, q_off, total_q, code, src_pos, gvalid, strike_src, rate_src, put_src):
+        """Channels + Greeks epilogue in one pass: the forward-fill index of (strike, interest_rate, callput) is computed
+        on the device and consumed by the eval kernel without leaving it."""
+        from . import engine
+        torch = engine.require_device()
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        ko, qo = d(knot_off), d(q_off)
+        fidx = engine.ffill_index_batch(d(src_pos), ko, d(gvalid), qo, int(total_q))
+        out, st, gr = engine.interp1d_greeks_batch(d(xk), d(yk), ko, qo, int(total_q), code, (0, 1, 2), fidx, (0, 1, 2),
+                                                   d(strike_src), d(rate_src), d(put_src))
+        return out.cpu().numpy(), st.cpu().numpy(), gr.cpu().numpy()
+
+
+def _greek_sources(frames_src, n_rows):
+    """Source-row arrays of the three option attributes the Greeks need, for symbols packed back to back.
+    frames_src: per symbol a dict column -> ndarray (only the on-lattice source rows).  Returns (valid uint8 [3, n],
+    strike f64, rate f64, put uint8 0 call / 1 put / 2 null).  A symbol WITHOUT the column gets the schema default
+    (interest_rate 0.0: schema.py:34; callput: call) -- except strike, without which there are no Greeks (NaN)."""
+    n = int(sum(n_rows))
+    valid = np.zeros((3, n), np.uint8); strike = np.full(n, np.nan); rate = np.zeros(n); put = np.zeros(n, np.uint8)
+    a = 0
+    for src, m in zip(frames_src, n_rows):
+        b = a + int(m)
+        if "strike" in src:
+            v = pd.to_numeric(pd.Series(src["strike"]), errors="coerce").to_numpy(np.float64, na_value=np.nan)
+            strike[a:b] = v; valid[0, a:b] = ~np.isnan(v)
+        if "interest_rate" in src:
+            v = pd.to_numeric(pd.Series(src["interest_rate"]), errors="coerce").to_numpy(np.float64, na_value=np.nan)
+            rate[a:b] = v; valid[1, a:b] = ~np.isnan(v)
+        else:
+            valid[1, a:b] = 1
+        if "callput" in src:
+            cp = pd.Series(src["callput"])
+            null = cp.isna().to_numpy()
+            is_call = cp.astype(str).str.lower().str.startswith("c").to_numpy()      # option_type == 'call' else put (greeks.py:24)
+            put[a:b] = np.where(null, 2, np.where(is_call, 0, 1)); valid[2, a:b] = ~null
+        else:
+            valid[2, a:b] = 1
+        a = b
+    return valid, strike, rate, put
+
 
 class _Prepared:
     __slots__ = ("df", "timeline", "pos", "rowlat", "M", "chan_src", "chan_needs", "chan_kind", "fill_cols",
@@ -85,10 +127,14 @@ class _Prepared:
 class IVInterpolator:
     """Core interpolation engine for IV data (MI355X-native)."""
 
-    def __init__(self, method: str = "linear", min_points: int = 10, backend=None):
+    def __init__(self, method: str = "linear", min_points: int = 10, backend=None, preserve_greeks: bool = False):
         self.method = method
         self.min_points = min_points
         self._backend = backend          # None -> HipBackend on first use
+        # reference config.py:46 `preserve_greeks` ("Recalculate Greeks after interpolation"): the reference declares the
+        # flag and the delta..rho columns (schema.py:36-40) but wires nothing up.  When set, every output row carries the
+        # five Black-Scholes Greeks of greeks.py:12-43, formed in the interpolation kernel's epilogue.
+        self.preserve_greeks = bool(preserve_greeks)
 
     # ------------------------------------------------------------------ public API
     def interpolate_symbol(self, symbol_data: pd.DataFrame) -> Optional[pd.DataFrame]:
@@ -121,7 +167,13 @@ class IVInterpolator:
         total_q = int(q_off[-1])
         xk = np.concatenate([p.pos for p in ps]).astype(np.float64)
         yk = np.stack([np.concatenate([p.chan_src[c] for p in ps]) for c in range(len(NUMERIC_COLS))])
-        out, status = be.interp1d_batch(xk, yk, src_off, q_off, total_q, code)
+        greeks = None
+        if self.preserve_greeks:
+            gvalid, ksrc, rsrc, psrc = _greek_sources([p.src_np for p in ps], n_src)
+            out, status, greeks = be.interp1d_greeks_batch(xk, yk, src_off, q_off, total_q, code, xk.astype(np.int64),
+                                                          gvalid, ksrc, rsrc, psrc)
+        else:
+            out, status = be.interp1d_batch(xk, yk, src_off, q_off, total_q, code)
         ncols = max((len(p.fill_cols) for p in ps), default=0)
         idx = None
         if ncols:
@@ -137,7 +189,8 @@ class IVInterpolator:
             try:
                 results[i] = self._assemble(p, out[:, q_off[k]:q_off[k + 1]], status[k],
                                             None if idx is None else idx[:, q_off[k]:q_off[k + 1]] - src_off[k],
-                                            None if idx is None else idx[:, q_off[k]:q_off[k + 1]] < 0)
+                                            None if idx is None else idx[:, q_off[k]:q_off[k + 1]] < 0,
+                                            None if greeks is None else greeks[:, q_off[k]:q_off[k + 1]])
             except EngineUnavailable:
                 raise
             except Exception as e:                                       # core.py:83-85
@@ -235,7 +288,14 @@ class IVInterpolator:
         for ci, k in enumerate(kinds):
             if k == "obj":
                 needs[:, ci] = False                                     # object dtype: Series.interpolate is a no-op
-        out, status = be.interp1d_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code)
+        greeks = None
+        if self.preserve_greeks:
+            srcg = {c: data[c].to_numpy()[src_rows] for c in ("strike", "interest_rate", "callput") if c in data.columns}
+            gvalid, ksrc, rsrc, psrc = _greek_sources([srcg], [len(src_rows)])
+            out, status, greeks = be.interp1d_greeks_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q,
+                                                          code, pos.astype(np.int64), gvalid, ksrc, rsrc, psrc)
+        else:
+            out, status = be.interp1d_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code)
         sym_ok = ~((status != ST_OK) & needs).any(1)                     # scipy would raise -> that symbol is None
         # ---- forward-fill gather index
         fill_cols = [c for c in FILL_COLS if c in data.columns]
@@ -294,6 +354,11 @@ class IVInterpolator:
         for c in REQUIRED[1:]:
             keep &= ~pd.isna(cols[c])
         cols["is_interpolated"] = sym_na
+        if greeks is not None:
+            for gi, gname in enumerate(GREEK_COLS):
+                cols[gname] = greeks[gi]
+                if gname not in out_cols:
+                    out_cols.append(gname)
         res = pd.DataFrame({c: cols[c] for c in out_cols}, copy=False)
         if not keep.all():
             res = res[keep].reset_index(drop=True)
@@ -371,7 +436,7 @@ class IVInterpolator:
         p.fill_valid = [(~pd.isna(p.src_np[c])).astype(np.uint8) for c in p.fill_cols]
         return p
 
-    def _assemble(self, p: _Prepared, out, status, fill_idx, fill_missing) -> Optional[pd.DataFrame]:
+    def _assemble(self, p: _Prepared, out, status, fill_idx, fill_missing, greeks=None) -> Optional[pd.DataFrame]:
         df, M = p.df, p.M
         q = len(p.pos)
         for c in range(len(NUMERIC_COLS)):
@@ -425,6 +490,11 @@ class IVInterpolator:
         order = ["date"] + [c for c in df.columns if c != "date"]
         if "is_interpolated" not in order:
             order.append("is_interpolated")
+        if greeks is not None:
+            for gi, gname in enumerate(GREEK_COLS):
+                cols[gname] = greeks[gi]
+                if gname not in order:
+                    order.append(gname)
         merged = pd.DataFrame({c: cols[c] for c in order}, copy=False)
         if not keep.all():
             merged = merged[keep]

@@ -10,7 +10,6 @@
 #include "../../include/ivs.h"
 #include "ivs_bridge.hpp"
 #include "ivs_candles.hpp"
-#include "ivs_greeks.hpp"
 #include "ivs_interp1d.hpp"
 #include "ivs_surface_dense.hpp"
 #include "ivs_surface_dense_var2.hpp"
@@ -87,28 +86,24 @@ size_t ivs_interp1d_workspace_bytes(int64_t total_knots, int64_t n_series, int32
     return ivs::interp1d_ws_bytes(total_knots, n_series, n_channels);
 }
 
-int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
-                           int64_t n_series, int32_t n_channels, int64_t total_knots,
-                           const double* xq, const int64_t* q_off, int64_t total_queries,
-                           double* out, int64_t out_stride, int32_t* status, int32_t method,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int interp1d_impl(const char* fn, const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
+                  int64_t n_series, int32_t n_channels, int64_t total_knots, const double* xq, const int64_t* q_off,
+                  int64_t total_queries, double* out, int64_t out_stride, int32_t* status, int32_t method, void* workspace,
+                  size_t workspace_bytes, void* stream, ivs::Interp1dParams& p) {
     g_err[0] = 0;
-    if (!valid_method(method)) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: unknown method %d", method);
-    if (n_series < 0 || n_channels < 0 || total_knots < 0 || total_queries < 0)
-        return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: negative size");
+    if (!valid_method(method)) return fail(IVS_EINVAL, "%s: unknown method %d", fn, method);
+    if (n_series < 0 || n_channels < 0 || total_knots < 0 || total_queries < 0) return fail(IVS_EINVAL, "%s: negative size", fn);
     if (n_series == 0 || n_channels == 0) return IVS_OK;
-    if (!knot_off || !q_off || !status) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: null offsets/status");
-    if (total_knots > 0 && (!xk || !yk)) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: null knots");
-    if (total_queries > 0 && !out) return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: null out");
+    if (!knot_off || !q_off || !status) return fail(IVS_EINVAL, "%s: null offsets/status", fn);
+    if (total_knots > 0 && (!xk || !yk)) return fail(IVS_EINVAL, "%s: null knots", fn);
+    if (total_queries > 0 && !out) return fail(IVS_EINVAL, "%s: null out", fn);
     if (yk_stride < total_knots || out_stride < total_queries)
-        return fail(IVS_EINVAL, "ivs_interp1d_batch_f64: channel stride smaller than row length");
+        return fail(IVS_EINVAL, "%s: channel stride smaller than row length", fn);
     if (n_series * (int64_t)n_channels > 0x7fffffffLL || (total_queries + 255) / 256 > 0x7fffffffLL)
-        return fail(IVS_ERANGE, "ivs_interp1d_batch_f64: batch too large for one launch");
+        return fail(IVS_ERANGE, "%s: batch too large for one launch", fn);
     size_t need = ivs::interp1d_ws_bytes(total_knots, n_series, n_channels);
-    if (!workspace || workspace_bytes < need)
-        return fail(IVS_ENOMEM, "ivs_interp1d_batch_f64: workspace %zu < %zu bytes", workspace_bytes, need);
-
-    ivs::Interp1dParams p;
+    if (!workspace || workspace_bytes < need) return fail(IVS_ENOMEM, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
     p.xk = xk; p.yk = yk; p.yk_stride = yk_stride; p.knot_off = knot_off;
     p.S = n_series; p.C = n_channels; p.total_knots = total_knots;
     p.xq = xq; p.q_off = q_off; p.total_q = total_queries;
@@ -126,6 +121,47 @@ int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride
         rc = check_launch("interp1d_eval_kernel");
     }
     return rc;
+}
+}  // namespace
+
+int ivs_interp1d_batch_f64(const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
+                           int64_t n_series, int32_t n_channels, int64_t total_knots,
+                           const double* xq, const int64_t* q_off, int64_t total_queries,
+                           double* out, int64_t out_stride, int32_t* status, int32_t method,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    ivs::Interp1dParams p{};
+    p.greeks = nullptr;
+    return interp1d_impl("ivs_interp1d_batch_f64", xk, yk, yk_stride, knot_off, n_series, n_channels, total_knots, xq, q_off,
+                         total_queries, out, out_stride, status, method, workspace, workspace_bytes, stream, p);
+}
+
+int ivs_interp1d_greeks_batch_f64(const double* xk, const double* yk, int64_t yk_stride, const int64_t* knot_off,
+                                  int64_t n_series, int32_t n_channels, int64_t total_knots,
+                                  const double* xq, const int64_t* q_off, int64_t total_queries,
+                                  double* out, int64_t out_stride, int32_t* status, int32_t method,
+                                  int32_t ch_iv, int32_t ch_underlying, int32_t ch_ttm,
+                                  const int32_t* fill_idx, int64_t fill_stride, int32_t row_strike, int32_t row_rate,
+                                  int32_t row_callput, const double* strike_src, const double* rate_src,
+                                  const uint8_t* is_put_src, double* greeks, int64_t greeks_stride,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    const char* fn = "ivs_interp1d_greeks_batch_f64";
+    g_err[0] = 0;
+    if (n_series > 0 && n_channels > 0 && total_queries > 0) {
+        if (!greeks || greeks_stride < total_queries) return fail(IVS_EINVAL, "%s: null / short greeks output", fn);
+        if (ch_iv < 0 || ch_iv >= n_channels || ch_underlying < 0 || ch_underlying >= n_channels || ch_ttm < 0 || ch_ttm >= n_channels)
+            return fail(IVS_EINVAL, "%s: channel numbers outside [0, %d)", fn, n_channels);
+        if ((row_strike >= 0 || row_rate >= 0 || row_callput >= 0) && (!fill_idx || fill_stride < total_queries))
+            return fail(IVS_EINVAL, "%s: null / short fill index", fn);
+        if ((row_strike >= 0 && !strike_src) || (row_rate >= 0 && !rate_src) || (row_callput >= 0 && !is_put_src))
+            return fail(IVS_EINVAL, "%s: a present column needs its source array", fn);
+    }
+    ivs::Interp1dParams p{};
+    p.fidx = fill_idx; p.fidx_stride = fill_stride; p.fi_strike = row_strike; p.fi_rate = row_rate; p.fi_put = row_callput;
+    p.strike_src = strike_src; p.rate_src = rate_src; p.put_src = is_put_src;
+    p.ch_iv = ch_iv; p.ch_S = ch_underlying; p.ch_T = ch_ttm;
+    p.greeks = greeks; p.greeks_stride = greeks_stride;
+    return interp1d_impl(fn, xk, yk, yk_stride, knot_off, n_series, n_channels, total_knots, xq, q_off, total_queries, out,
+                         out_stride, status, method, workspace, workspace_bytes, stream, p);
 }
 
 int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const uint8_t* valid, int64_t valid_stride,

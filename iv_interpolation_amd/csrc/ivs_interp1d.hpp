@@ -8,6 +8,7 @@
 //   coalesced store.  Queries default to the integer lattice 0..m-1 (the reference's RangeIndex).
 #pragma once
 #include "ivs_device.hpp"
+#include "ivs_greeks.hpp"
 
 namespace ivs {
 
@@ -17,6 +18,14 @@ struct Interp1dParams {
     const double* xq; const int64_t* q_off; int64_t total_q;
     double* out; int64_t out_stride; int32_t* status; int method;
     double* wx; double* wy; double* ws; double* wcp; int32_t* wn;
+    // optional Greeks epilogue (config.interpolation.preserve_greeks; greeks == nullptr: off).  The channel values of a row are
+    // still in registers when its delta..rho are formed; strike / interest_rate / callput come from the source rows
+    // through the forward-fill gather index (rows fi_* of fidx; -1 = column absent: strike -> NaN Greeks, rate -> 0.0,
+    // callput -> call).
+    const int32_t* fidx; int64_t fidx_stride; int fi_strike, fi_rate, fi_put;
+    const double* strike_src; const double* rate_src; const uint8_t* put_src;      // put_src: 0 call, 1 put, 2 null
+    int ch_iv, ch_S, ch_T;
+    double* greeks; int64_t greeks_stride;
 };
 
 __host__ __device__ inline size_t interp1d_ws_bytes(int64_t total_knots, int64_t S, int C) {
@@ -141,6 +150,11 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
         xq[u] = !active[u] ? qnan() : (p.xq ? p.xq[g] : (double)(g - p.q_off[s]));
     }
     const int method = p.method;
+    double gv[3][E1_RPT];                                      // Greeks epilogue: iv, S, T of the thread's rows
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int u = 0; u < E1_RPT; ++u) gv[k][u] = qnan();
     const bool cubic = method_is_cubic(method) || method_is_poly(method);      // a per-knot table rides along with (x, y)
     const bool lerp_method = method == IVS_LINEAR || method == IVS_SLINEAR;
     const int minkn = method_min_knots(method);
@@ -174,8 +188,38 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
                 const int j = find_interval(x, n, xq[u]);
                 if (staged && lerp_method) r = eval_linear_slopes(x, y, sl, n, j, xq[u], method == IVS_LINEAR);
                 else r = eval_method(method, x, y, sl, n, j, xq[u]);
+                // a row that IS a knot of this channel keeps its source cell in the reference's frame
+                if (p.greeks && j >= 0 && x(j) == xq[u]) r = y(j);
+            } else if (p.greeks && active[u] && n > 0) {       // too few knots to interpolate: knots keep their cells
+                CView x{gx, 1}, y{gy, 1};
+                const int j = find_interval(x, n, xq[u]);
+                if (j >= 0 && x(j) == xq[u]) r = y(j);
             }
             if (active[u]) p.out[c * p.out_stride + g0 + u * 256 + tid] = r;
+            if (p.greeks) {
+                if (c == p.ch_iv) gv[0][u] = r;
+                if (c == p.ch_S) gv[1][u] = r;
+                if (c == p.ch_T) gv[2][u] = r;
+            }
+        }
+    }
+    if (p.greeks) {
+#pragma unroll
+        for (int u = 0; u < E1_RPT; ++u) {
+            if (!active[u]) continue;
+            const int64_t g = g0 + u * 256 + tid;
+            const double nanv = qnan();
+            double K = nanv, rate = 0.0;
+            int put = 0;
+            if (p.fi_strike >= 0) { const int32_t i = p.fidx[p.fi_strike * p.fidx_stride + g]; if (i >= 0) K = p.strike_src[i]; }
+            if (p.fi_rate >= 0) { const int32_t i = p.fidx[p.fi_rate * p.fidx_stride + g]; rate = i >= 0 ? p.rate_src[i] : nanv; }
+            if (p.fi_put >= 0) { const int32_t i = p.fidx[p.fi_put * p.fidx_stride + g]; put = i >= 0 ? p.put_src[i] : 2; }
+            double de, ga, th, ve, rh;
+            bs_greeks_one(gv[1][u], K, gv[2][u], rate, gv[0][u], put == 1, de, ga, th, ve, rh);
+            if (put == 2) { de = nanv; ga = nanv; th = nanv; ve = nanv; rh = nanv; }        // null callput: undefined
+            p.greeks[0 * p.greeks_stride + g] = de; p.greeks[1 * p.greeks_stride + g] = ga;
+            p.greeks[2 * p.greeks_stride + g] = th; p.greeks[3 * p.greeks_stride + g] = ve;
+            p.greeks[4 * p.greeks_stride + g] = rh;
         }
     }
 }

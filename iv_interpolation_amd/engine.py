@@ -148,6 +148,34 @@ def interp1d_batch(xk, yk, knot_off, q_off, total_q: int, method, xq=None, strea
     return out, status
 
 
+def interp1d_greeks_batch(xk, yk, knot_off, q_off, total_q: int, method, channels, fidx, rows, strike_src, rate_src,
+                          put_src, stream=None):
+    """interp1d_batch with the Greeks epilogue (ivs_interp1d_greeks_batch_f64).  channels = (ch_iv, ch_S, ch_T); fidx int32
+    [n_cols, total_q] from ffill_index_batch; rows = (row_strike, row_rate, row_callput) inside fidx or -1; *_src = source
+    columns (float64, float64, uint8 0/1/2) or None.  Returns (out [C,total_q], status [S,C], greeks [5,total_q])."""
+    torch = require_device()
+    lib = _lib.load()
+    code = _lib.METHOD_CODES[method] if isinstance(method, str) else int(method)
+    xk = _f64(torch, xk, "xk"); yk = _f64(torch, yk, "yk")
+    Cn, TK = yk.shape
+    S = knot_off.numel() - 1
+    dev = yk.device
+    out = torch.empty((Cn, total_q), dtype=torch.float64, device=dev)
+    greeks = torch.empty((5, total_q), dtype=torch.float64, device=dev)
+    status = torch.zeros((S, Cn), dtype=torch.int32, device=dev)
+    wsb = lib.ivs_interp1d_workspace_bytes(TK, S, Cn)
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+    fidx = None if fidx is None else fidx.contiguous()
+    rc = lib.ivs_interp1d_greeks_batch_f64(_ptr(xk), _ptr(yk), TK, _ptr(knot_off), S, Cn, TK, None, _ptr(q_off), total_q,
+                                           _ptr(out), total_q, _ptr(status), code, int(channels[0]), int(channels[1]),
+                                           int(channels[2]), _ptr(fidx), 0 if fidx is None else fidx.shape[1],
+                                           int(rows[0]), int(rows[1]), int(rows[2]), _ptr(strike_src), _ptr(rate_src),
+                                           _ptr(put_src), _ptr(greeks), total_q, _ptr(ws), ws.numel() * 8,
+                                           _stream(torch, stream))
+    _lib.check(rc, "ivs_interp1d_greeks_batch_f64")
+    return out, status, greeks
+
+
 def ffill_index_batch(src_pos, src_off, valid, q_off, total_q: int, stream=None):
     """valid uint8 [n_cols, total_src] -> int32 [n_cols, total_q] flat source-row index or -1."""
     torch = require_device()

@@ -14,6 +14,30 @@ class OracleBackend:
     def interp1d_batch(self, xk, yk, knot_off, q_off, total_q, code):
         return O.interp1d_batch(xk, yk, knot_off, None, q_off, code)
 
+    def interp1d_greeks_batch(self, xk, yk, knot_off, q_off, total_q, code, src_pos, gvalid, strike_src, rate_src, put_src):
+        """Oracle twin of the fused call: channels by ivs_oracle, rows that are knots of a channel keep the source cell,
+        strike / rate / callput through the forward-fill index, Greeks by greeks_oracle."""
+        import greeks_oracle as GO
+        out, status = O.interp1d_batch(xk, yk, knot_off, None, q_off, code)
+        fidx = self.ffill_index_batch(src_pos, knot_off, gvalid, q_off, total_q)
+        vals = out.copy()
+        for s in range(len(knot_off) - 1):
+            a, b = int(knot_off[s]), int(knot_off[s + 1])
+            rows = int(q_off[s]) + src_pos[a:b]
+            for c in range(yk.shape[0]):
+                src = yk[c, a:b]
+                ok = ~np.isnan(src)
+                vals[c, rows[ok]] = src[ok]
+        nanv = np.nan
+        K = np.where(fidx[0] >= 0, strike_src[np.clip(fidx[0], 0, None)], nanv)
+        r = np.where(fidx[1] >= 0, rate_src[np.clip(fidx[1], 0, None)], nanv)
+        put = np.where(fidx[2] >= 0, put_src[np.clip(fidx[2], 0, None)], 2)
+        with np.errstate(all="ignore"):
+            g = GO.calculate_greeks(vals[1], K, vals[2], r, vals[0], put == 1)
+        gr = np.stack([g[k] for k in ("delta", "gamma", "theta", "vega", "rho")])
+        gr[:, put == 2] = np.nan
+        return out, status, gr
+
     def ffill_index_batch(self, src_pos, src_off, valid, q_off, total_q):
         n_cols = valid.shape[0]
         idx = np.full((n_cols, total_q), -1, np.int32)

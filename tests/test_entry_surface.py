@@ -33,7 +33,10 @@ def test_complete_pipeline_task1(tmp_path):
     out = store.read_output(syms[0])
     src = store.read_symbol(syms[0])
     assert len(out) == (len(src) - 1) * 60 + 1                       # hourly -> 1-minute lattice
-    assert list(out.columns)[-2:] == ["is_interpolated", "batch_id"] and not out["is_interpolated"].any()
+    # config.interpolation.preserve_greeks defaults to True (reference config.py:46): the rows carry delta..rho
+    assert list(out.columns)[-7:] == ["is_interpolated", "delta", "gamma", "theta", "vega", "rho", "batch_id"]
+    assert not out["is_interpolated"].any() and out[["delta", "gamma", "theta", "vega", "rho"]].notna().all().all()
+    assert ((out["delta"] > 0) & (out["delta"] < 1) & (out["gamma"] > 0) & (out["vega"] > 0)).all()      # calls
     # knots are reproduced exactly, interior rows are np.interp of the neighbours
     on = out[out["date"].isin(src["date"])]
     assert np.array_equal(on["iv"].to_numpy(), src["iv"].to_numpy())

@@ -438,12 +438,15 @@ def test_polynomial_methods_on_gpu_vs_oracle_and_knot_limit(method):
     from iv_interpolation_amd import IVInterpolator
     from iv_interpolation_amd.frame_store import synthetic_symbol
     import ref_symbol
-    for n, seed in ((10, 1), (17, 2), (25, 3), (32, 4)):
+    # tolerance relative to the curve's largest magnitude, by knot count: the conditioning of one polynomial through n
+    # (almost) equispaced knots grows like 2^n -- at 32 knots scipy's own two routes differ by 1e-8 and its barycentric
+    # weights move by 2e-9 from run to run (unseeded node permutation), see golden_io.method_tolerances
+    for n, seed, tol in ((10, 1, 1e-11), (17, 2, 1e-10), (25, 3, 1e-9), (32, 4, 1e-6)):
         df = synthetic_symbol(f"p{n}", n, seed=seed)
         df.loc[3, "iv"] = np.nan
         got = IVInterpolator(method, 2).interpolate_symbol(df)
         exp = ref_symbol.interpolate_symbol(df, method, 2)
-        assert_symbol_frame(got, exp, name=f"{method} n={n}", rtol=1e-12, atol=1e-13, scale_rtol=1e-9)
+        assert_symbol_frame(got, exp, name=f"{method} n={n}", rtol=1e-12, atol=1e-13, scale_rtol=tol)
     assert IVInterpolator(method, 2).interpolate_symbol(synthetic_symbol("p40", 40, seed=5)) is None
 
 

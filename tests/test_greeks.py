@@ -49,3 +49,53 @@ def test_hip_greeks_against_reference_golden_and_oracle():
     ref = G.calculate_greeks(*[t[idx].cpu().numpy() for t in (S, K, T, rr, sg)], put[idx].cpu().numpy().astype(bool))
     for k in ref:
         assert np.allclose(out[k][idx].cpu().numpy(), ref[k], rtol=RTOL, atol=1e-300), k
+
+
+# ---- the epilogue wired to `preserve_greeks` (reference config.py:46; columns schema.py:36-40): frames through the
+# interpolator with the flag set, against the real reference's interpolate_symbol + calculate_greeks on the same frames
+gf = np.load(os.path.join(GOLDEN, "greeks_frames.npz"))
+GREEKS = ["delta", "gamma", "theta", "vega", "rho"]
+
+
+def _gf_input(name):
+    import pandas as pd
+    from golden_io import _dec
+    cols = [str(c) for c in gf[f"{name}/in_columns"]]
+    return pd.DataFrame({c: _dec(gf, f"{name}/in", c, str(gf[f"{name}/in_tag/{c}"])) for c in cols})
+
+
+def _check_greeks_frame(got, name):
+    assert got is not None and len(got) == int(gf[f"{name}/rows"]), name
+    assert list(got.columns[-5:]) == GREEKS, list(got.columns)
+    assert np.array_equal(got["date"].to_numpy().astype("datetime64[ns]").astype(np.int64), gf[f"{name}/date"])
+    for c in ("iv", "underlying_price", "time_to_maturity"):
+        assert np.allclose(got[c].to_numpy(np.float64), gf[f"{name}/out/{c}"], rtol=1e-12, atol=1e-13, equal_nan=True), (name, c)
+    for c in GREEKS:
+        g, e = got[c].to_numpy(np.float64), gf[f"{name}/greeks/{c}"]
+        assert np.array_equal(np.isnan(g), np.isnan(e)), (name, c)
+        # Greeks amplify the 1e-15 differences of the interpolated inputs (d1 divides by sigma sqrt(T)): 1e-10 relative
+        assert np.allclose(g, e, rtol=1e-10, atol=1e-14, equal_nan=True), (name, c, np.nanmax(np.abs(g - e)))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in gf["names"]])
+def test_preserve_greeks_host_logic_against_reference_golden(name):
+    from oracle_backend import OracleBackend
+    from iv_interpolation_amd import IVInterpolator
+    method = str(gf["methods"][list(gf["names"]).index(name)])
+    df = _gf_input(name)
+    iv = IVInterpolator(method, 10, backend=OracleBackend(), preserve_greeks=True)
+    _check_greeks_frame(iv.interpolate_symbol(df), name)
+    _check_greeks_frame(iv.interpolate_frame(df), name)
+    plain = IVInterpolator(method, 10, backend=OracleBackend()).interpolate_symbol(df)
+    assert not set(GREEKS) & set(plain.columns)                      # flag off: the reference's 14 columns, nothing else
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [str(n) for n in gf["names"]])
+def test_preserve_greeks_epilogue_on_gpu_against_reference_golden(name):
+    from iv_interpolation_amd import IVInterpolator
+    method = str(gf["methods"][list(gf["names"]).index(name)])
+    df = _gf_input(name)
+    iv = IVInterpolator(method, 10, preserve_greeks=True)
+    _check_greeks_frame(iv.interpolate_symbol(df), name)
+    _check_greeks_frame(iv.interpolate_frame(df), name)
