@@ -128,6 +128,29 @@ int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const 
                           int32_t* idx_out, int64_t out_stride, void* stream);
 
 /*
+ * Columnar egress of the forward-filled columns (core.py:64-68 for every symbol at once): column c of the long output
+ * frame is gathered on the device with the index ivs_ffill_index_batch produced,
+ *   out[c][g] = idx[idx_row[c]][g] >= 0 ? src[c][idx[idx_row[c]][g]] : missing     (missing: NaN / -1)
+ * f64 for numeric columns, i32 for the codes of object columns (symbol, callput); idx_row [n_cols] (device) names the
+ * row of idx each column uses.
+ */
+int ivs_gather_rows_f64(const double* src, int64_t src_stride, const int32_t* idx, int64_t idx_stride, const int32_t* idx_row,
+                        int32_t n_cols, int64_t n, double* out, int64_t out_stride, void* stream);
+int ivs_gather_rows_i32(const int32_t* src, int64_t src_stride, const int32_t* idx, int64_t idx_stride, const int32_t* idx_row,
+                        int32_t n_cols, int64_t n, int32_t* out, int64_t out_stride, void* stream);
+
+/*
+ * Row bookkeeping of the long output frame on the device: date_ns[g] = first_ns[s] + (g - q_off[s]) minutes (s = the
+ * symbol of row g; valid for symbols without duplicate timestamps) and keep[g] = the row survives the reference's dropna
+ * (core.py:74) in a symbol that did not fail (status[s][c] != 0 on a channel with needs[s][c] -> the symbol is None).
+ * chan [n_channels][chan_stride] = the merged channel columns (out of ivs_interp1d_batch_f64), sym_code [total_queries] =
+ * gathered symbol codes (negative = null) or NULL.
+ */
+int ivs_frame_rows(const int64_t* q_off, int64_t n_series, int64_t total_queries, const int64_t* first_ns,
+                   const double* chan, int64_t chan_stride, int32_t n_channels, const int32_t* sym_code,
+                   const int32_t* status, const uint8_t* needs, int64_t* date_ns, uint8_t* keep, void* stream);
+
+/*
  * Batch of (strike x maturity) surfaces: strike pass then maturity pass, each pass the
  * 1-D operator above (this repository's documented composition).
  *

@@ -58,6 +58,9 @@ SIGNATURES = {
                                                 _i32, _i32, _i32, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i64,
                                                 _p, _sz, _p]),
     "ivs_ffill_index_batch": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i64, _i64, _p, _i64, _p]),
+    "ivs_gather_rows_f64": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i64, _p, _i64, _p]),
+    "ivs_gather_rows_i32": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i64, _p, _i64, _p]),
+    "ivs_frame_rows": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "ivs_bs_greeks_f64": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "ivs_candle_aggregate_f64": (C.c_int, [_p] * 7 + [_i64, _i64, _i64] + [_p] * 8),
     "ivs_bridge_workspace_bytes": (C.c_size_t, [_i64]),

@@ -90,6 +90,92 @@ class HipBackend:
         return out.cpu().numpy(), st.cpu().numpy(), gr.cpu().numpy()
 
 
+    def frame_columns(self, pos, chan, src_off, q_off, total_q, code, valid, fsrc, f_rows, csrc, c_rows, host_rows, greek,
+                      rows_info=None):
+        """Everything interpolate_frame needs from the device in ONE round trip: the three merged channel columns, the
+        forward-filled numeric columns (gathered on the device), the codes of the forward-filled object columns, the raw
+        gather-index rows the host still wants (`host_rows`), optionally the Greeks.  Results land in pinned host memory
+        through asynchronous copies behind the kernels (one synchronisation); the NumPy arrays returned are views of it."""
+        from . import engine
+        torch = engine.require_device()
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        ko, qo = d(src_off), d(q_off)
+        pos_d = d(pos)
+        fidx = engine.ffill_index_batch(pos_d, ko, d(valid), qo, int(total_q)) if valid.shape[0] else None
+        yk = d(np.stack(chan)); xk = pos_d.to(torch.float64)
+        gr = None
+        if greek is not None:
+            gvalid, ksrc, rsrc, psrc = greek
+            gidx = engine.ffill_index_batch(pos_d, ko, d(gvalid), qo, int(total_q))
+            out, st, gr = engine.interp1d_greeks_batch(xk, yk, ko, qo, int(total_q), code, (0, 1, 2), gidx, (0, 1, 2),
+                                                       d(ksrc), d(rsrc), d(psrc))
+        else:
+            out, st = engine.interp1d_batch(xk, yk, ko, qo, int(total_q), code)
+        F = engine.gather_rows(d(fsrc), fidx, d(np.asarray(f_rows, np.int32))) if len(f_rows) else None
+        Cc = engine.gather_rows(d(csrc), fidx, d(np.asarray(c_rows, np.int32))) if len(c_rows) else None
+        n64 = 3 + (len(f_rows) if F is not None else 0) + (5 if gr is not None else 0)
+        h64 = torch.empty((n64, int(total_q)), dtype=torch.float64, pin_memory=True)
+        h64[:3].copy_(out, non_blocking=True)
+        k = 3
+        if F is not None:
+            h64[k:k + len(f_rows)].copy_(F, non_blocking=True); k += len(f_rows)
+        if gr is not None:
+            h64[k:k + 5].copy_(gr, non_blocking=True)
+        dates_h = keep_h = None
+        if rows_info is not None:                                  # timestamps + keep flags formed on the device
+            first_ns, needs, sym_row = rows_info
+            sym_code = Cc[sym_row] if (Cc is not None and sym_row is not None) else None
+            dts, kp = engine.frame_rows(qo, d(first_ns), out, sym_code, st, d(needs.astype(np.uint8)))
+            dates_h = torch.empty(int(total_q), dtype=torch.int64, pin_memory=True); dates_h.copy_(dts, non_blocking=True)
+            keep_h = torch.empty(int(total_q), dtype=torch.uint8, pin_memory=True); keep_h.copy_(kp, non_blocking=True)
+        n32 = (len(c_rows) if Cc is not None else 0) + len(host_rows)
+        h32 = torch.empty((max(n32, 1), int(total_q)), dtype=torch.int32, pin_memory=True)
+        j = 0
+        if Cc is not None:
+            h32[:len(c_rows)].copy_(Cc, non_blocking=True); j = len(c_rows)
+        for r in host_rows:
+            h32[j].copy_(fidx[r], non_blocking=True); j += 1
+        st_h = st.cpu()                                            # synchronises the stream: every copy above is complete
+        a64, a32 = h64.numpy(), h32.numpy()
+        res = {"chan": a64[:3], "status": st_h.numpy(), "F": a64[3:3 + len(f_rows)] if F is not None else None,
+               "C": a32[:len(c_rows)] if Cc is not None else None,
+               "rows": {r: a32[(len(c_rows) if Cc is not None else 0) + i] for i, r in enumerate(host_rows)},
+               "greeks": a64[n64 - 5:] if gr is not None else None,
+               "date_ns": None if dates_h is None else dates_h.numpy(),
+               "keep": None if keep_h is None else keep_h.numpy().view(np.bool_)}
+        return res
+
+
+def _frame_columns_generic(be, pos, chan, src_off, q_off, total_q, code, valid, fsrc, f_rows, csrc, c_rows, host_rows, greek,
+                           rows_info=None):
+    """frame_columns for backends that only answer the two primitive calls (the oracle backend of the CPU tests): same
+    results, formed with NumPy."""
+    gr = None
+    if greek is not None:
+        gvalid, ksrc, rsrc, psrc = greek
+        out, status, gr = be.interp1d_greeks_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code,
+                                                  pos.astype(np.int64), gvalid, ksrc, rsrc, psrc)
+    else:
+        out, status = be.interp1d_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code)
+    out = np.array(out, copy=True)
+    ks = np.repeat(np.arange(len(src_off) - 1), np.diff(src_off))
+    gpos = q_off[:-1][ks] + pos
+    for ci in range(3):                                                # rows that are knots keep their source cell
+        okk = ~np.isnan(chan[ci])
+        out[ci, gpos[okk]] = chan[ci][okk]
+    fidx = be.ffill_index_batch(pos.astype(np.int64), src_off, valid, q_off, total_q) if valid.shape[0] else None
+
+    def take(src, rows, missing):
+        o = np.empty((len(rows), total_q), src.dtype)
+        for k, r in enumerate(rows):
+            i = fidx[r]
+            o[k] = np.where(i >= 0, src[k][np.clip(i, 0, None)], missing)
+        return o
+    return {"chan": out, "status": status, "F": take(fsrc, f_rows, np.nan) if len(f_rows) else None,
+            "C": take(csrc, c_rows, -1) if len(c_rows) else None, "rows": {r: fidx[r] for r in host_rows}, "greeks": gr,
+            "date_ns": None, "keep": None}
+
+
 def _greek_sources(frames_src, n_rows):
     """Source-row arrays of the three option attributes the Greeks need, for symbols packed back to back.
     frames_src: per symbol a dict column -> ndarray (only the on-lattice source rows).  Returns (valid uint8 [3, n],
@@ -288,34 +374,53 @@ class IVInterpolator:
         for ci, k in enumerate(kinds):
             if k == "obj":
                 needs[:, ci] = False                                     # object dtype: Series.interpolate is a no-op
-        greeks = None
-        if self.preserve_greeks:
-            srcg = {c: data[c].to_numpy()[src_rows] for c in ("strike", "interest_rate", "callput") if c in data.columns}
-            gvalid, ksrc, rsrc, psrc = _greek_sources([srcg], [len(src_rows)])
-            out, status, greeks = be.interp1d_greeks_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q,
-                                                          code, pos.astype(np.int64), gvalid, ksrc, rsrc, psrc)
-        else:
-            out, status = be.interp1d_batch(pos.astype(np.float64), np.stack(chan), src_off, q_off, total_q, code)
-        sym_ok = ~((status != ST_OK) & needs).any(1)                     # scipy would raise -> that symbol is None
-        # ---- forward-fill gather index
+        # ---- forward-filled columns: numeric ones are gathered on the device, object ones travel as integer codes
         fill_cols = [c for c in FILL_COLS if c in data.columns]
         src_np = {c: data[c].to_numpy()[src_rows] for c in cols_in}
-        valid = np.stack([(~pd.isna(src_np[c])).astype(np.uint8) for c in fill_cols])
-        fidx = be.ffill_index_batch(pos.astype(np.int64), src_off, valid, q_off, total_q)
+        valid = (np.stack([(~pd.isna(src_np[c])).astype(np.uint8) for c in fill_cols]) if fill_cols
+                 else np.zeros((0, len(src_rows)), np.uint8))
+        f_names = [c for c in fill_cols if src_np[c].dtype.kind == "f"]
+        o_names = [c for c in fill_cols if src_np[c].dtype == object]
+        h_names = [c for c in fill_cols if c not in f_names and c not in o_names]      # ints, bools, datetimes: host gather
+        fsrc = (np.stack([src_np[c].astype(np.float64, copy=False) for c in f_names]) if f_names
+                else np.zeros((0, len(src_rows))))
+        cats, codes = {}, []
+        for c in o_names:
+            if c == "symbol":
+                cd, cat = sym_codes[src_rows].astype(np.int32), np.asarray(sym_uniques, dtype=object)
+            else:
+                cd, cat = pd.factorize(src_np[c], use_na_sentinel=True)
+                cd = cd.astype(np.int32); cat = np.asarray(cat, dtype=object)
+            cats[c] = cat; codes.append(cd)
+        csrc = np.stack(codes) if codes else np.zeros((0, len(src_rows)), np.int32)
+        greek = None
+        if self.preserve_greeks:
+            srcg = {c: src_np[c] for c in ("strike", "interest_rate", "callput") if c in src_np}
+            greek = _greek_sources([srcg], [len(src_rows)])
+        dup = ~first
+        rows_info = (first_ns[kept].astype(np.int64), needs, o_names.index("symbol") if "symbol" in o_names else None)
+        args = (pos.astype(np.int64), chan, src_off, q_off, total_q, code, valid, fsrc, [fill_cols.index(c) for c in f_names],
+                csrc, [fill_cols.index(c) for c in o_names], [fill_cols.index(c) for c in h_names], greek, rows_info)
+        fc = be.frame_columns(*args) if hasattr(be, "frame_columns") else _frame_columns_generic(be, *args)
+        out, status, greeks = fc["chan"], fc["status"], fc["greeks"]
+        sym_ok = ~((status != ST_OK) & needs).any(1)                     # scipy would raise -> that symbol is None
         # ---- assemble the long output
-        sym_of_row = np.repeat(np.arange(S), M)
+        sym_of_row = None
         gpos = q_off[:-1][ks] + pos                                      # global output row of every source row
         nothing_missing = bool((M == q).all())
         lat_off = np.concatenate([[0], np.cumsum(m0k)])
-        cnt = np.ones(int(lat_off[-1]), np.int64)
-        dup = ~first
-        if dup.any():
-            np.add.at(cnt, lat_off[:-1][ks[dup]] + lat[dup], 1)          # duplicates multiply the timeline row (R7)
-            glat = np.repeat(np.arange(int(lat_off[-1])), cnt)
+        if fc["date_ns"] is not None and not dup.any():
+            date_ns = fc["date_ns"]                                      # formed on the device (no duplicate timestamps)
         else:
-            glat = np.arange(total_q)
-        lat_in_sym = glat - lat_off[:-1][sym_of_row]
-        date_ns = first_ns[kept][sym_of_row] + lat_in_sym * MINUTE_NS
+            sym_of_row = np.repeat(np.arange(S), M)
+            if dup.any():
+                cnt = np.ones(int(lat_off[-1]), np.int64)
+                np.add.at(cnt, lat_off[:-1][ks[dup]] + lat[dup], 1)      # duplicates multiply the timeline row (R7)
+                glat = np.repeat(np.arange(int(lat_off[-1])), cnt)
+                lat_in_sym = glat - lat_off[:-1][sym_of_row]
+            else:
+                lat_in_sym = np.arange(total_q) - q_off[:-1][sym_of_row]
+            date_ns = first_ns[kept][sym_of_row] + lat_in_sym * MINUTE_NS
         dates = pd.DatetimeIndex(date_ns.view("datetime64[ns]"))
         if tz is not None:
             dates = dates.tz_localize("UTC").tz_convert(tz)
@@ -331,17 +436,21 @@ class IVInterpolator:
                     merged[gpos] = v
                     cols[name] = merged
                     continue
-                merged = np.full(total_q, np.nan)
-                merged[gpos] = chan[ci]
-                fill = np.isnan(merged) & needs[sym_of_row, ci]
-                merged = np.where(fill, out[ci], merged)
+                merged = out[ci]                                         # knots keep their cells, the rest is interpolated
+                # (a column pandas leaves alone -- no NaN at all, or nothing but NaN -- comes back as its own cells)
                 if nothing_missing and int_dtype is not None:
                     merged = merged.astype(int_dtype)
                 else:
                     merged = _chan_finish(merged, kinds[ci], data[name].dtype)
                 cols[name] = merged
-            elif name in fill_cols:
-                cols[name] = _gather(v, fidx[fill_cols.index(name)].astype(np.int64), int_dtype, nothing_missing)
+            elif name in f_names:
+                col = fc["F"][f_names.index(name)]
+                cols[name] = col if v.dtype == np.float64 else col.astype(v.dtype)
+            elif name in o_names:
+                cat = cats[name]
+                cols[name] = np.append(cat, np.nan)[fc["C"][o_names.index(name)]]      # code -1 -> the appended NaN
+            elif name in h_names:
+                cols[name] = _gather(v, fc["rows"][fill_cols.index(name)].astype(np.int64), int_dtype, nothing_missing)
             else:
                 if raw_idx is None:
                     raw_idx = np.full(total_q, -1, np.int64)
@@ -349,10 +458,18 @@ class IVInterpolator:
                 cols[name] = _gather(v, raw_idx, int_dtype, nothing_missing)
         # the forward-fill index only ever points at VALID source cells, so "symbol is null" == "no source row yet"
         # (an integer compare instead of pd.isna over millions of Python strings)
-        sym_na = (fidx[fill_cols.index("symbol")] < 0) if "symbol" in fill_cols else pd.isna(cols["symbol"])
-        keep = ~sym_na & sym_ok[sym_of_row]
-        for c in REQUIRED[1:]:
-            keep &= ~pd.isna(cols[c])
+        if "symbol" in o_names:
+            sym_na = fc["C"][o_names.index("symbol")] < 0
+        else:
+            sym_na = np.asarray(pd.isna(cols["symbol"]))
+        if fc["keep"] is not None and all(k != "obj" for k in kinds):
+            keep = fc["keep"]                                            # formed on the device
+        else:
+            if sym_of_row is None:
+                sym_of_row = np.repeat(np.arange(S), M)
+            keep = ~sym_na & sym_ok[sym_of_row]
+            for c in REQUIRED[1:]:
+                keep &= ~np.asarray(pd.isna(cols[c]))
         cols["is_interpolated"] = sym_na
         if greeks is not None:
             for gi, gname in enumerate(GREEK_COLS):

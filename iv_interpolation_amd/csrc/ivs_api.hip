@@ -180,6 +180,56 @@ int ivs_ffill_index_batch(const int64_t* src_pos, const int64_t* src_off, const 
     return check_launch("ffill_index_kernel");
 }
 
+extern "C++" {
+namespace {
+template <class T>
+int gather_impl(const char* fn, const void* src, int64_t src_stride, const int32_t* idx, int64_t idx_stride, const int32_t* idx_row,
+                int32_t n_cols, int64_t n, void* out, int64_t out_stride, T missing, void* stream) {
+    g_err[0] = 0;
+    if (n_cols < 0 || n < 0) return fail(IVS_EINVAL, "%s: negative size", fn);
+    if (n_cols == 0 || n == 0) return IVS_OK;
+    if (!src || !idx || !idx_row || !out) return fail(IVS_EINVAL, "%s: null pointer", fn);
+    if (idx_stride < n || out_stride < n) return fail(IVS_EINVAL, "%s: stride smaller than row count", fn);
+    if (src_stride > 0x7fffffffLL) return fail(IVS_ERANGE, "%s: %lld source rows exceed the int32 gather index", fn, (long long)src_stride);
+    ivs::GatherParams p{src, src_stride, idx, idx_stride, idx_row, n_cols, n, out, out_stride};
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)num_cu() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ivs::gather_rows_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, missing);
+    return check_launch(fn);
+}
+}  // namespace
+}  // extern "C++"
+
+int ivs_gather_rows_f64(const double* src, int64_t src_stride, const int32_t* idx, int64_t idx_stride, const int32_t* idx_row,
+                        int32_t n_cols, int64_t n, double* out, int64_t out_stride, void* stream) {
+    return gather_impl<double>("ivs_gather_rows_f64", src, src_stride, idx, idx_stride, idx_row, n_cols, n, out, out_stride,
+                               __builtin_nan(""), stream);
+}
+
+int ivs_gather_rows_i32(const int32_t* src, int64_t src_stride, const int32_t* idx, int64_t idx_stride, const int32_t* idx_row,
+                        int32_t n_cols, int64_t n, int32_t* out, int64_t out_stride, void* stream) {
+    return gather_impl<int32_t>("ivs_gather_rows_i32", src, src_stride, idx, idx_stride, idx_row, n_cols, n, out, out_stride,
+                                (int32_t)-1, stream);
+}
+
+int ivs_frame_rows(const int64_t* q_off, int64_t n_series, int64_t total_queries, const int64_t* first_ns,
+                   const double* chan, int64_t chan_stride, int32_t n_channels, const int32_t* sym_code,
+                   const int32_t* status, const uint8_t* needs, int64_t* date_ns, uint8_t* keep, void* stream) {
+    g_err[0] = 0;
+    if (n_series < 0 || total_queries < 0 || n_channels < 0) return fail(IVS_EINVAL, "ivs_frame_rows: negative size");
+    if (n_series == 0 || total_queries == 0) return IVS_OK;
+    if (!q_off || !first_ns || !date_ns || !keep || (n_channels > 0 && (!chan || !status || !needs)))
+        return fail(IVS_EINVAL, "ivs_frame_rows: null pointer");
+    if (chan_stride < total_queries) return fail(IVS_EINVAL, "ivs_frame_rows: chan_stride < total_queries");
+    ivs::FrameRowsParams p{q_off, n_series, total_queries, first_ns, chan, chan_stride, n_channels, sym_code, status, needs, date_ns, keep};
+    int64_t blocks = (total_queries + 255) / 256;
+    const int64_t cap = (int64_t)num_cu() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ivs::frame_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return check_launch("frame_rows_kernel");
+}
+
 int ivs_candle_aggregate_f64(const int64_t* ts_ns, const double* open, const double* high, const double* low,
                              const double* close, const double* volume, const int64_t* series_off, int64_t n_series,
                              int64_t n_rows, int64_t freq_ns, int64_t* out_ts, double* out_open, double* out_high,

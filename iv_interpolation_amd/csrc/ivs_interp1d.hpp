@@ -188,9 +188,10 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
                 const int j = find_interval(x, n, xq[u]);
                 if (staged && lerp_method) r = eval_linear_slopes(x, y, sl, n, j, xq[u], method == IVS_LINEAR);
                 else r = eval_method(method, x, y, sl, n, j, xq[u]);
-                // a row that IS a knot of this channel keeps its source cell in the reference's frame
-                if (p.greeks && j >= 0 && x(j) == xq[u]) r = y(j);
-            } else if (p.greeks && active[u] && n > 0) {       // too few knots to interpolate: knots keep their cells
+                // a row that IS a knot of this channel keeps its source cell in the reference's frame (the interpolant
+                // reproduces it anyway, except the Newton form of 'krogh' in the last bits): `out` is the merged column
+                if (j >= 0 && x(j) == xq[u]) r = y(j);
+            } else if (active[u] && n > 0) {                   // too few knots to interpolate: knots keep their cells
                 CView x{gx, 1}, y{gy, 1};
                 const int j = find_interval(x, n, xq[u]);
                 if (j >= 0 && x(j) == xq[u]) r = y(j);
@@ -279,6 +280,48 @@ __global__ __launch_bounds__(256) void ffill_index_kernel(FfillParams p) {
             else { const uint8_t* v = p.valid + c * p.valid_stride + lo0; while (j >= 0 && !v[j]) --j; }
             p.idx_out[c * p.out_stride + g] = j >= 0 ? (int32_t)(lo0 + j) : -1;
         }
+    }
+}
+
+// ---- columnar egress: forward-filled columns gathered on the device, so that the host receives the
+// finished columns of the long output frame instead of an index to chase through its own memory.
+//   out[c][g] = idx[idx_row[c]][g] >= 0 ? src[c][idx] : missing      (missing = NaN for f64 columns, -1 for code columns)
+struct GatherParams {
+    const void* src; int64_t src_stride; const int32_t* idx; int64_t idx_stride; const int32_t* idx_row; int n_cols;
+    int64_t n; void* out; int64_t out_stride;
+};
+template <class T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherParams p, T missing) {
+    const T* src = static_cast<const T*>(p.src);
+    T* out = static_cast<T*>(p.out);
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < p.n; g += (int64_t)gridDim.x * 256) {
+        for (int c = 0; c < p.n_cols; ++c) {
+            const int32_t i = p.idx[(int64_t)p.idx_row[c] * p.idx_stride + g];
+            out[(int64_t)c * p.out_stride + g] = i >= 0 ? src[(int64_t)c * p.src_stride + i] : missing;
+        }
+    }
+}
+
+// Per output row of the long frame: its timestamp (first timestamp of the symbol + one minute per lattice step; only
+// meaningful for symbols without duplicate timestamps, the host falls back otherwise) and whether the row survives the
+// reference's dropna (core.py:74: symbol, iv, underlying_price, time_to_maturity all present) in a symbol that did not
+// fail (a channel that needed interpolation but had too few knots makes the whole symbol None, core.py:83-85).
+struct FrameRowsParams {
+    const int64_t* q_off; int64_t S; int64_t total_q; const int64_t* first_ns;
+    const double* chan; int64_t chan_stride; int n_chan; const int32_t* sym_code;
+    const int32_t* status; const uint8_t* needs;             // [S][n_chan] each
+    int64_t* date_ns; uint8_t* keep;
+};
+__global__ __launch_bounds__(256) void frame_rows_kernel(FrameRowsParams p) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < p.total_q; g += (int64_t)gridDim.x * 256) {
+        const int64_t s = series_of(p.q_off, p.S, g);
+        p.date_ns[g] = p.first_ns[s] + (g - p.q_off[s]) * 60000000000LL;
+        bool ok = p.sym_code ? p.sym_code[g] >= 0 : true;
+        for (int c = 0; c < p.n_chan; ++c) {
+            ok = ok && !__builtin_isnan(p.chan[(int64_t)c * p.chan_stride + g]);
+            ok = ok && !(p.needs[s * p.n_chan + c] && p.status[s * p.n_chan + c] != IVS_ST_OK);
+        }
+        p.keep[g] = ok ? 1 : 0;
     }
 }
 

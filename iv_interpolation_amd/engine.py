@@ -189,6 +189,34 @@ def ffill_index_batch(src_pos, src_off, valid, q_off, total_q: int, stream=None)
     return idx
 
 
+def gather_rows(src, idx, idx_row, stream=None):
+    """Columnar egress: out[c][g] = src[c][idx[idx_row[c]][g]] (NaN / -1 where the index is negative).  src float64 or int32
+    [n_cols, n_src]; idx int32 [rows, n]; idx_row int32 [n_cols] (device)."""
+    torch = require_device()
+    lib = _lib.load()
+    n_cols, n_src = src.shape
+    n = idx.shape[1]
+    out = torch.empty((n_cols, n), dtype=src.dtype, device=src.device)
+    fn = lib.ivs_gather_rows_f64 if src.dtype == torch.float64 else lib.ivs_gather_rows_i32
+    rc = fn(_ptr(src.contiguous()), n_src, _ptr(idx), idx.shape[1], _ptr(idx_row), n_cols, n, _ptr(out), n, _stream(torch, stream))
+    _lib.check(rc, "ivs_gather_rows")
+    return out
+
+
+def frame_rows(q_off, first_ns, chan, sym_code, status, needs, stream=None):
+    """Per output row: timestamp (int64 ns) and the dropna / failed-symbol keep flag (ivs_frame_rows)."""
+    torch = require_device()
+    lib = _lib.load()
+    S = q_off.numel() - 1
+    Cn, total_q = chan.shape
+    dates = torch.empty(total_q, dtype=torch.int64, device=chan.device)
+    keep = torch.empty(total_q, dtype=torch.uint8, device=chan.device)
+    rc = lib.ivs_frame_rows(_ptr(q_off), S, total_q, _ptr(first_ns), _ptr(chan), total_q, Cn, _ptr(sym_code), _ptr(status.contiguous()),
+                            _ptr(needs.contiguous()), _ptr(dates), _ptr(keep), _stream(torch, stream))
+    _lib.check(rc, "ivs_frame_rows")
+    return dates, keep
+
+
 def bs_greeks(S, K, T, r, sigma, is_put=None, default_is_put: bool = False, stream=None):
     """Black-Scholes Greeks on the device.  All inputs CUDA float64 tensors of one shape (is_put: uint8 or None).
     Returns dict(delta, gamma, theta, vega, rho) of tensors with that shape."""

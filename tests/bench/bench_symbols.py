@@ -44,9 +44,16 @@ import pandas as pd
 big = [synthetic_symbol(f"s{i:05d}", n, seed=i) for i in range(2048)]
 long = pd.concat(big, ignore_index=True)
 iv.interpolate_frame(long.iloc[: 64 * n])
-t0 = time.perf_counter(); lf = iv.interpolate_frame(long); dtf = time.perf_counter() - t0
-res["end_to_end_frame"] = {"symbols": 2048, "symbols_per_s": 2048 / dtf, "rows_per_s": len(lf) / dtf,
-                           "note": "one long DataFrame in, one long DataFrame out (interpolate_frame)"}
+t0 = time.perf_counter(); lf = iv.interpolate_frame(long); dt_first = time.perf_counter() - t0
+del lf                                              # the result's pinned host blocks return to torch's caching allocator
+reps = []
+for _ in range(5):
+    t0 = time.perf_counter(); lf = iv.interpolate_frame(long); reps.append(time.perf_counter() - t0); n_rows = len(lf); del lf
+dtf = sorted(reps)[len(reps) // 2]
+res["end_to_end_frame"] = {"symbols": 2048, "symbols_per_s": 2048 / dtf, "rows_per_s": n_rows / dtf,
+                           "first_call_symbols_per_s": 2048 / dt_first,
+                           "note": "one long DataFrame in, one long DataFrame out (interpolate_frame); median of 5 calls in steady "
+                                   "state (pinned result buffers recycled by the caching host allocator), first call separately"}
 t0 = time.perf_counter(); [iv.interpolate_symbol(f) for f in frames[:32]]; dt1 = time.perf_counter() - t0
 res["end_to_end_single"] = {"symbols_per_s": 32 / dt1}
 import ref_symbol
