@@ -79,7 +79,9 @@ int         ivs_device_count(void);   /* number of visible HIP devices (0 if non
  *   knot_off [S+1]               CSR offsets into xk / yk
  *   xq  [total_queries] or NULL  query coordinates; NULL = 0,1,..,m_s-1 per series (the reference's RangeIndex)
  *   q_off [S+1]                  CSR offsets into xq / out
- *   out [C][out_stride]          result of channel c, query i at out[c*out_stride + i]
+ *   out [C][out_stride]          result of channel c, query i at out[c*out_stride + i]; a query that coincides with a
+ *                                knot of the channel returns that knot's value (the merged column of the reference's
+ *                                frame), also when status reports too few knots to interpolate between them
  *   status [S*C]                 IVS_ST_* per (series, channel)
  *   workspace                    ivs_interp1d_workspace_bytes(total_knots, S, C) bytes of device memory
  */

@@ -9,6 +9,7 @@
 #pragma once
 #include "ivs_device.hpp"
 #include "ivs_greeks.hpp"
+#include "ivs_surface_dense.hpp"      // DPP helpers, scan_mat2
 
 namespace ivs {
 
@@ -33,6 +34,97 @@ __host__ __device__ inline size_t interp1d_ws_bytes(int64_t total_knots, int64_t
 }
 
 constexpr int P1_STAGE = 512;    // knots per (series, channel) whose slope solve runs out of LDS
+
+// ---- wave-level scans of affine maps f_i(x) = A_i x + B_i over 64 lanes (lanes without a map carry the identity (1, 0)).
+// prefix: v_i = (f_i o f_{i-1} o ... o f_0)(x_in); suffix: v_i = (f_i o f_{i+1} o ... o f_63)(x_in).  Inside a row of
+// 16 lanes the compositions are formed with DPP shifts, the four rows are then chained through v_readlane.
+__device__ __forceinline__ double affine_prefix64(double A, double B, double x_in, int lane) {
+#define IVS_AFF_STEP(SH)                                                                            \
+    { const double a = dpp_f64<DPP_ROW_SHR(SH)>(1.0, A), b = dpp0_f64<DPP_ROW_SHR(SH)>(B); B = __builtin_fma(A, b, B); A = A * a; }
+    IVS_AFF_STEP(1) IVS_AFF_STEP(2) IVS_AFF_STEP(4) IVS_AFF_STEP(8)
+#undef IVS_AFF_STEP
+    double v = 0.0, x = x_in;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double t = __builtin_fma(A, x, B);
+        v = (lane >> 4) == r ? t : v;
+        x = readlane_f64(t, 16 * r + 15);
+    }
+    return v;
+}
+__device__ __forceinline__ double affine_suffix64(double A, double B, double x_in, int lane) {
+#define IVS_AFF_STEP(SH)                                                                            \
+    { const double a = dpp_f64<DPP_ROW_SHL(SH)>(1.0, A), b = dpp0_f64<DPP_ROW_SHL(SH)>(B); B = __builtin_fma(A, b, B); A = A * a; }
+    IVS_AFF_STEP(1) IVS_AFF_STEP(2) IVS_AFF_STEP(4) IVS_AFF_STEP(8)
+#undef IVS_AFF_STEP
+    double v = 0.0, x = x_in;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+        const double t = __builtin_fma(A, x, B);
+        v = (lane >> 4) == r ? t : v;
+        x = readlane_f64(t, 16 * r);
+    }
+    return v;
+}
+
+// Not-a-knot slopes of ONE series-channel (n >= 4 knots staged in LDS px / py) by one wavefront: blocks of 64 knots in
+// turn -- pivots by the Moebius scan of the dense kernels (factor_tables), the forward and the backward recurrence as
+// affine scans -- instead of a serial Thomas recurrence on one thread.  cp_s / dp_s: LDS scratch of n entries (every
+// lane re-reads only what it wrote itself); the slopes end up in dp_s.
+__device__ __forceinline__ void nak_slopes_wave(const double* px, const double* py, int n, int lane, double* cp_s, double* dp_s) {
+    const int nb = (n + 63) >> 6;
+    double c00 = 1.0, c01 = 0.0, c10 = 0.0, c11 = 1.0, carry_crb = 0.0, dp_carry = 0.0;
+    for (int blk = 0; blk < nb; ++blk) {
+        const int i = blk * 64 + lane;
+        const bool in = i < n;
+        const int ii = in ? i : n - 1;
+        const int ip = ii + 1 < n ? ii + 1 : n - 1, ipp = ii + 2 < n ? ii + 2 : n - 1, im = ii > 0 ? ii - 1 : 0, imm = ii > 1 ? ii - 2 : 0;
+        const double x0 = px[ii], xp = px[ip], xpp = px[ipp], xm = px[im], xmm = px[imm];
+        const double y0 = py[ii], yp = py[ip], ypp = py[ipp], ym = py[im], ymm = py[imm];
+        const double dxc = xp - x0, dxm = x0 - xm, dxp = xpp - xp, dxmm = xm - xmm;
+        const bool first = i == 0, last = i == n - 1;
+        double a, b, c, r;
+        if (first) {
+            const double d = dxc + dxp, d0 = (yp - y0) * refined_rcp(dxc), d1 = (ypp - yp) * refined_rcp(dxp);
+            a = 0.0; b = dxp; c = d; r = ((dxc + 2.0 * d) * dxp * d0 + dxc * dxc * d1) * refined_rcp(d);
+        } else if (last) {
+            const double d = dxmm + dxm, dA = (ym - ymm) * refined_rcp(dxmm), dB = (y0 - ym) * refined_rcp(dxm);
+            a = d; b = dxmm; c = 0.0; r = (dxm * dxm * dA + (2.0 * d + dxm) * dxmm * dB) * refined_rcp(d);
+        } else {
+            const double dm = (y0 - ym) * refined_rcp(dxm), dc = (yp - y0) * refined_rcp(dxc);
+            a = dxc; b = 2.0 * (dxm + dxc); c = dxm; r = 3.0 * (dxc * dm + dxm * dc);
+        }
+        if (!in) { a = 0.0; b = 1.0; c = 0.0; r = 0.0; }
+        const double rb = refined_rcp(b);
+        const double crb = c * rb;
+        double crb_prev = dpp0_f64<DPP_WAVE_SHR1>(crb);
+        if (blk > 0 && lane == 0) crb_prev = carry_crb;
+        const bool ident = first || !in;
+        const double g = ident ? 0.0 : a * rb * crb_prev;
+        double p00 = 1.0, p01 = ident ? 0.0 : -g, p10 = ident ? 0.0 : 1.0, p11 = ident ? 1.0 : 0.0;
+        scan_mat2<64>(p00, p01, p10, p11, lane);
+        if (blk > 0) {
+            const double n00 = p00 * c00 + p01 * c10, n01 = p00 * c01 + p01 * c11;
+            const double n10 = p10 * c00 + p11 * c10, n11 = p10 * c01 + p11 * c11;
+            p00 = n00; p01 = n01; p10 = n10; p11 = n11;
+        }
+        const double rw = first ? rb : (p10 + p11) * rb * refined_rcp(p00 + p01);      // 1 / w_i
+        const double al = a * rw, cp = c * rw, rr = r * rw;
+        const double dp = affine_prefix64(in ? -al : 1.0, in ? rr : 0.0, dp_carry, lane);     // dp_i = rr_i - al_i dp_{i-1}
+        if (in) { cp_s[i] = cp; dp_s[i] = dp; }
+        c00 = readlane_f64(p00, 63); c01 = readlane_f64(p01, 63); c10 = readlane_f64(p10, 63); c11 = readlane_f64(p11, 63);
+        carry_crb = readlane_f64(crb, 63); dp_carry = readlane_f64(dp, 63);
+    }
+    double s_carry = 0.0;
+    for (int blk = nb - 1; blk >= 0; --blk) {
+        const int i = blk * 64 + lane;
+        const bool in = i < n;
+        const double cp = in ? cp_s[i] : 0.0, dp = in ? dp_s[i] : 0.0;
+        const double sv = affine_suffix64(in ? -cp : 1.0, in ? dp : 0.0, s_carry, lane);      // s_i = dp_i - cp_i s_{i+1}
+        if (in) dp_s[i] = sv;
+        s_carry = readlane_f64(sv, 0);
+    }
+}
 
 __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p) {
     __shared__ int wave_cnt[4];
@@ -90,10 +182,13 @@ __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p)
         return;
     }
     if (solve && base <= P1_STAGE) {
-        // the serial recurrence reads its knots from LDS (one global round trip per step would dominate)
+        // the recurrences read their knots from LDS (one global round trip per step would dominate)
         for (int i = tid; i < (int)base; i += 256) { px[i] = wx[i]; py[i] = wy[i]; }
         __syncthreads();
-        if (tid == 0) {
+        const bool nak = p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE;
+        if (nak && base >= 4) {
+            if (wave == 0) nak_slopes_wave(px, py, (int)base, lane, pc, ps);     // one wavefront, scans instead of a serial chain
+        } else if (tid == 0) {      // local-slope methods, the quadratic B-spline, 2- and 3-knot cubicspline: one thread
             CView xv{px, 1}, yv{py, 1};
             View sv{ps, 1}, cv{pc, 1};
             method_slopes(p.method, xv, yv, sv, cv, (int)base);

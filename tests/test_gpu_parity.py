@@ -450,6 +450,39 @@ def test_polynomial_methods_on_gpu_vs_oracle_and_knot_limit(method):
     assert IVInterpolator(method, 2).interpolate_symbol(synthetic_symbol("p40", 40, seed=5)) is None
 
 
+@pytest.mark.parametrize("method", ["cubic", "cubicspline"])
+def test_interp1d_wavefront_solve_block_boundaries(method):
+    """The not-a-knot solve of the 1-D prepare kernel runs on one wavefront in blocks of 64 knots (Moebius pivot scan +
+    affine forward / backward scans, carries from block to block); beyond 512 knots the serial path takes over.  Knot
+    counts around every boundary, NaN knots, uneven spacing, three channels with different masks -- against the oracle."""
+    import torch
+    from iv_interpolation_amd import engine
+    r = np.random.default_rng(7)
+    sizes = [4, 5, 63, 64, 65, 127, 128, 129, 200, 511, 512, 513, 700]
+    xs, ys, qs, koff, qoff = [], [], [], [0], [0]
+    for n in sizes:
+        x = np.cumsum(r.integers(1, 9, n)).astype(np.float64)
+        y = np.stack([np.sin(x / 17.0) + 0.05 * r.standard_normal(n), 25000 + np.cumsum(r.normal(0, 40, n)), 0.05 - x * 1e-6])
+        y[0, r.random(n) < 0.15] = np.nan; y[1, :2] = np.nan; y[2, -3:] = np.nan
+        q = np.arange(0, int(x[-1]) + 3, dtype=np.float64)
+        xs.append(x); ys.append(y); qs.append(q); koff.append(koff[-1] + n); qoff.append(qoff[-1] + len(q))
+    xk = np.concatenate(xs); yk = np.concatenate(ys, axis=1); xq = np.concatenate(qs)
+    out, st = engine.interp1d_batch(dev(xk), dev(yk), dev(np.array(koff, np.int64)), dev(np.array(qoff, np.int64)), len(xq),
+                                    method, xq=dev(xq))
+    ref, rst = O.interp1d_batch(xk, yk, np.array(koff), xq, np.array(qoff), METHODS[method])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    got = out.cpu().numpy()
+    for k, n in enumerate(sizes):
+        sl = slice(qoff[k], qoff[k + 1])
+        for c in range(3):
+            if rst[k, c] != 0:
+                continue          # too few knots: nothing is interpolated (rows ON a knot still return the knot's cell)
+            assert np.array_equal(np.isnan(got[c, sl]), np.isnan(ref[c, sl])), (method, n, c)
+            scale = np.nanmax(np.abs(ref[c, sl])) if np.isfinite(ref[c, sl]).any() else 1.0
+            err = np.nanmax(np.abs(got[c, sl] - ref[c, sl])) if np.isfinite(ref[c, sl]).any() else 0.0
+            assert err <= 1e-11 * max(scale, 1.0), (method, n, c, err, scale)
+
+
 def test_interpolate_frame_against_reference_goldens_on_gpu():
     """(f)1 at frame level on the HIP path: the concatenated golden inputs of the symbol cases through
     IVInterpolator.interpolate_frame against the concatenated outputs of the REAL reference (core.py:16-85 per symbol;
