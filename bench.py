@@ -151,6 +151,10 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
                                                         a.nk if workload == a.workload else 0)
     if nK != nK0:
         desc = desc.replace("64 strikes", f"{nK} strikes").replace("(64x16)", f"({nK}x16)")
+    if a.nan_frac > 0 and workload == a.workload:
+        g = torch.Generator(device="cuda"); g.manual_seed(synth.BASE_SEED + 77 + rank)
+        d["sigma"][torch.rand(d["sigma"].shape, generator=g, device="cuda") < a.nan_frac] = float("nan")
+        desc += f", {a.nan_frac:.0%} of the quotes missing (NaN)"
     Kq_h, Tq_h = synth.query_grids(mK, mT, nT)
     Kq = torch.from_numpy(Kq_h).cuda(); Tq = torch.from_numpy(Tq_h).cuda()
     out = torch.empty((B, mT, mK), dtype=torch.float64, device="cuda")
@@ -204,7 +208,7 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
     assert int(status.max()) == 0
 
     sample = None
-    if want_sample and not ragged and a.check > 0:
+    if want_sample and not ragged and a.check > 0 and a.nan_frac == 0:
         idx = torch.linspace(0, B - 1, a.check, device="cuda").long()
         sample = (d["K"][idx].cpu().numpy(), d["T"].cpu().numpy(), d["sigma"][idx].cpu().numpy(), Kq_h, Tq_h,
                   out[idx].cpu().numpy())
@@ -265,6 +269,8 @@ def main():
                     help="N > 1 only.  strong (default) = ONE --batch split over the ranks (BASELINE config 3); weak = --batch per rank")
     ap.add_argument("--nk", type=int, default=0, help="override the strike count of a uniform workload (variable-shape kernel)")
     ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--nan-frac", type=float, default=0.0,
+                    help="fraction of quotes set to NaN (= missing): every row then has its own knot set (masked second-pass kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-4 / config-5 sub-results of the N = 1 line")
     ap.add_argument("--check", type=int, default=256, help="surfaces compared with the oracle after the timed region")
@@ -312,7 +318,7 @@ def main():
                      backend, scaling, want_sample=(rank == 0 and world == 1 and not a.no_cpu_baseline))
 
     others = {}
-    if world == 1 and not a.no_other_configs and a.workload == "cfg3" and not a.nk and not a.force_generic:
+    if world == 1 and not a.no_other_configs and a.workload == "cfg3" and not a.nk and not a.force_generic and a.nan_frac == 0:
         # the driver runs the default line only: carry the other two BASELINE configs along (a few steps each)
         for wl, st in (("cfg4", 5), ("cfg5", 5)):
             o = run_workload(torch, engine, synth, sharding, None, a, wl, a.method, a.batch, st, 2, 0, 1, backend, "weak")

@@ -1,0 +1,252 @@
+// Surfaces with MISSING quotes (NaN in sigma), 64 strikes x 16 maturities, not-a-knot methods: the fast second pass.
+//
+// A missing quote changes the KNOT SET of its row, so every row has its own tridiagonal system -- the shared
+// factorisation of the dense kernels does not apply -- and until now any NaN sent the surface to the correctness-first
+// generic kernel (18 M surfaces/s: lane t runs row t's serial Thomas recurrence, 51 KB of LDS = 3 wavefronts per CU,
+// one binary search per row and query, lane-private columns in LDS).  This kernel keeps the generic kernel's per-row
+// solve but removes what made it slow:
+//   * rows are compacted by wave ballot; besides the compacted quotes each row keeps a RANK table (valid knots at or
+//     below strike k, one byte) so that the interval of a query in ANY row is one LDS byte away from the interval in
+//     the full strike grid -- no per-row binary searches;
+//   * the per-row system is eliminated from BOTH ends at once by two lanes ("burn at both ends"): the not-a-knot system
+//     is symmetric under reversal of the strike axis (x -> -x, slopes change sign), so lane (row, 1) runs the same
+//     recurrence on the mirrored row, the two meet in the middle, exchange their last (c', d') pair through one DPP
+//     swap, close the 2 x 2 system and back-substitute their halves: half the dependent steps, no extra arithmetic,
+//     the elimination's c' coefficients stay in registers (32 per lane);
+//   * strike-pass values stay in registers; a column whose values are all there takes the dense register solve with the
+//     batch-wide tables from the scalar cache, the few columns with a missing value (a row that lost its outermost
+//     quotes does not reach the outermost output strikes) are solved in place by the generic per-column recurrence.
+//     Surfaces with a row of fewer than 4 quotes, a column with too few values or more than 8 masked columns keep
+//     their "redo" tag and fall through to the generic kernel (third launch, cheap when nothing is left).
+// LDS: two planes [16][66] + two byte tables = 19.5 KB = 8 wavefronts per CU.
+// Scope: uniform 64 x 16 batches, T / Tq shared, mK <= 64, cubic / cubicspline; runs in FILTER mode behind the dense /
+// row-pass kernel (only surfaces tagged with the sentinel).
+#pragma once
+#include "ivs_surface_dense.hpp"
+
+namespace ivs {
+
+constexpr int MK_RS = 66;                          // row stride (doubles) of the compacted planes
+__host__ __device__ constexpr size_t masked_lds_bytes() { return (size_t)(2 * DT * MK_RS + DK) * 8 + 2 * DT * DK + DT * 4; }
+
+// knots of one (possibly mirrored) compacted row: x(j), y(j) for j counted from the lane's own end
+struct MaskedRow {
+    const double* xs; const double* y; int n; bool mir;     // xs: the row's compacted strikes (S plane until overwritten)
+    __device__ __forceinline__ int at(int j) const { return mir ? n - 1 - j : j; }
+    __device__ __forceinline__ double x(int j) const { const double v = xs[at(j)]; return mir ? -v : v; }
+    __device__ __forceinline__ double yv(int j) const { return y[at(j)]; }
+};
+struct MaskedT { const double* T; const uint8_t* idx; __device__ __forceinline__ double operator()(int i) const { return T[idx[i]]; } };
+constexpr int MK_MAXCOL = 8;                      // masked output columns handled in place per surface (more: generic kernel)
+// accessors of a compacted row for eval_cubic
+struct MaskedX { const double* Ksh; const uint8_t* idx; __device__ __forceinline__ double operator()(int i) const { return Ksh[idx[i]]; } };
+
+template <int METHOD>
+__global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) {
+    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot methods only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int mT = p.mT, mK = p.mK;
+    double* YC = reinterpret_cast<double*>(smem);
+    double* SS = YC + DT * MK_RS;
+    double* Ksh = SS + DT * MK_RS;
+    uint8_t* IDX = reinterpret_cast<uint8_t*>(Ksh + DK);
+    uint8_t* RANK = IDX + DT * DK;
+    int* NROW = reinterpret_cast<int*>(RANK + DT * DK);
+    const double nanv = __builtin_nan("");
+    auto nostamp = [](int) {};
+
+    TqTables tt;
+    const double* TTp = nullptr;
+    const double* Wp = nullptr;
+    tq_from_shared(p.tqs, tt, TTp, Wp);
+
+    const bool kq_shared = p.kq_stride == 0;
+    const bool act = lane < mK;
+    double xq = (kq_shared && act) ? p.Kq[lane] : nanv;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+
+    const int64_t n_outer = (p.B + 63) / 64;
+    for (int64_t ob = blockIdx.x; ob < n_outer; ob += gridDim.x) {
+      const int64_t bi = ob * 64 + lane;
+      const bool tagged = bi < p.B &&
+          reinterpret_cast<const unsigned long long*>(p.out + bi * (int64_t)mT * mK)[0] == REDO_SENTINEL;
+      unsigned long long todo = __ballot(tagged);
+      while (todo) {
+        const int bit = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t b = ob * 64 + bit;
+        const double* sb = p.sigma + b * (int64_t)(DT * DK);
+        double* outb = p.out + b * (int64_t)mT * mK;
+        double v[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) v[t] = sb[t * DK + lane];
+        const double kx = p.K[b * p.k_stride + lane];
+        if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;
+        __syncthreads();                                   // the previous surface's readers are done with LDS
+        Ksh[lane] = kx;
+        // ---- compact every row by ballot; RANK[t][k] = valid knots of row t at or below strike k
+        bool give_up = tt.unsorted != 0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const bool valid = (v[t] - v[t]) == 0.0;           // finite: neither NaN (missing) nor an infinity
+            const unsigned long long m = __ballot(valid);
+            const int rank = __popcll(m & lt_mask);
+            // compacted quotes, their strike numbers, and -- in the S plane, until the elimination overwrites them knot by
+            // knot -- the compacted strikes themselves (saves the index -> strike indirection inside the recurrence)
+            if (valid) { YC[t * MK_RS + rank] = v[t]; IDX[t * DK + rank] = (uint8_t)lane; SS[t * MK_RS + rank] = kx; }
+            RANK[t * DK + lane] = (uint8_t)__popcll(m & le_mask);
+            const int nt = __popcll(m);
+            if (lane == 0) NROW[t] = nt;
+            give_up = give_up || nt < 4;                       // too few knots (or an empty row): the generic kernel's business
+        }
+        if (give_up) continue;                                 // wave-uniform; the sentinel stays, the generic pass redoes it
+        __syncthreads();
+        // ---- per-row not-a-knot solve, two lanes per row eliminating from the two ends (lanes 0..31)
+        if (lane < 32) {
+            const int t = lane >> 1;
+            const bool mir = (lane & 1) != 0;
+            const int n = NROW[t];
+            const int m_top = n >> 1;
+            const int cnt = mir ? n - m_top : m_top;           // rows this lane eliminates: 2 .. 32
+            double* srow = SS + t * MK_RS;
+            const MaskedRow R{srow, YC + t * MK_RS, n, mir};
+            double cpv[32];
+            double xm = R.x(0), xc = R.x(1), xp = R.x(2);
+            double ym = R.yv(0), yc = R.yv(1), yp = R.yv(2);
+            double dxm = xc - xm, dxc = xp - xc;
+            double dlm = (yc - ym) * refined_rcp(dxm), dlc = (yp - yc) * refined_rcp(dxc);
+            double cprev, dprev;
+            {   // row 0 (not-a-knot): [dx1, x2 - x0], rhs = ((dx0 + 2d) dx1 d0 + dx0^2 d1) / d
+                const double d = xp - xm;
+                const double rhs = ((dxm + 2.0 * d) * dxc * dlm + dxm * dxm * dlc) * refined_rcp(d);
+                const double rdx1 = refined_rcp(dxc);
+                cprev = d * rdx1; dprev = rhs * rdx1;
+                __builtin_amdgcn_wave_barrier();               // x(0..2) of BOTH lanes are in registers before anything is stored
+                cpv[0] = cprev; srow[R.at(0)] = dprev;
+                __builtin_amdgcn_wave_barrier();
+            }
+            int cmax = cnt;                                    // uniform bound of the unrolled loop
+            cmax = max(cmax, __shfl_xor(cmax, 1)); cmax = max(cmax, __shfl_xor(cmax, 2)); cmax = max(cmax, __shfl_xor(cmax, 4));
+            cmax = max(cmax, __shfl_xor(cmax, 8)); cmax = max(cmax, __shfl_xor(cmax, 16));
+            cmax = __builtin_amdgcn_readfirstlane(cmax);
+#pragma unroll
+            for (int j = 1; j < 32; ++j) {
+                if (j < cmax) {                               // wave-uniform: whole steps are skipped
+                    // the knot two steps ahead is read BEFORE this step's result is stored: in a row with an odd knot
+                    // count the partner lane overwrites exactly that slot of the S plane in this very step
+                    double xn = 0.0, yn = 0.0;
+                    if (j + 1 < cnt) { xn = R.x(j + 2); yn = R.yv(j + 2); }
+                    __builtin_amdgcn_wave_barrier();
+                    if (j < cnt) {
+                        const double rhs = 3.0 * (dxc * dlm + dxm * dlc);
+                        const double rw = refined_rcp(2.0 * (dxm + dxc) - dxc * cprev);
+                        cprev = dxm * rw;
+                        dprev = (rhs - dxc * dprev) * rw;
+                        cpv[j] = cprev; srow[R.at(j)] = dprev;
+                        if (j + 1 < cnt) {
+                            xm = xc; xc = xp; xp = xn;
+                            ym = yc; yc = yp; yp = yn;
+                            dxm = dxc; dxc = xp - xc;
+                            dlm = dlc; dlc = (yp - yc) * refined_rcp(dxc);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // meet in the middle: own relation  s_own = d_own - c_own * s_other', partner's the same with roles swapped
+            const double c_oth = dpp_f64<DPP_QUAD_SWAP1>(cprev, cprev), d_oth = dpp_f64<DPP_QUAD_SWAP1>(dprev, dprev);
+            double sn = (dprev + cprev * d_oth) * refined_rcp(1.0 - cprev * c_oth);
+            srow[R.at(cnt - 1)] = mir ? -sn : sn;
+#pragma unroll
+            for (int j = 30; j >= 0; --j) {
+                if (j < cnt - 1) {
+                    sn = srow[R.at(j)] - cpv[j] * sn;
+                    srow[R.at(j)] = mir ? -sn : sn;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- strike evaluation (q-lane): interval in the full grid once, per row one RANK byte away
+        int jf = -1;
+        if (Ksh[0] <= xq) {
+            jf = 0;
+#pragma unroll
+            for (int m = 1; m < 8; ++m) jf += (Ksh[8 * m] <= xq) ? 8 : 0;
+#pragma unroll
+            for (int st = 4; st >= 1; st >>= 1) if (Ksh[jf + st] <= xq) jf += st;
+        }
+        double z[DT];
+        bool all_ok = true;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int n = NROW[t];
+            const int j = jf >= 0 ? (int)RANK[t * DK + jf] - 1 : -1;
+            const MaskedX X{Ksh, IDX + t * DK};
+            const CView Y{YC + t * MK_RS, 1}, S{SS + t * MK_RS, 1};
+            z[t] = eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
+            all_ok = all_ok && !__builtin_isnan(z[t]);
+        }
+        // ---- maturity direction.  A column whose strike-pass values are all there takes the dense register solve with the
+        // batch-wide tables; a column with a missing value (a row whose outermost quotes are gone does not reach the
+        // outermost output strikes) has its own maturity knot set: up to MK_MAXCOL of them are solved in place by the
+        // generic kernel's per-column recurrence, in slots carved out of the (now dead) quote plane.
+        const bool col_masked = act && !all_ok;
+        const unsigned long long mm = __ballot(col_masked);
+        if (mm != 0ull) {
+            if (__popcll(mm) > MK_MAXCOL) continue;            // the generic kernel redoes the surface
+            __syncthreads();                                   // every lane is done with the planes
+            double* Tsh = Ksh;                                 // 16 maturities
+            double* cz = YC; double* cs = YC + MK_MAXCOL * DT; double* ccp = YC + 2 * MK_MAXCOL * DT;
+            uint8_t* cti = IDX;
+            if (lane < DT) Tsh[lane] = p.T[lane];
+            const int slot = __popcll(mm & lt_mask);
+            int cn = 0;
+            if (col_masked) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+                    if (!__builtin_isnan(z[t])) { cz[slot * DT + cn] = z[t]; cti[slot * DT + cn] = (uint8_t)t; ++cn; }
+            }
+            if (__ballot(col_masked && cn > 0 && cn < method_min_knots(METHOD)) != 0ull) continue;    // too-few-knots status: generic kernel
+            __syncthreads();
+            if (col_masked) {
+                const MaskedT cx{Tsh, cti + slot * DT};
+                const CView cy{cz + slot * DT, 1};
+                View csv{cs + slot * DT, 1}, cpw{ccp + slot * DT, 1};
+                if (cn >= 2) method_slopes(METHOD, cx, cy, csv, cpw, cn);
+                const CView csr{cs + slot * DT, 1};
+                int jc = -1;
+                for (int tq = 0; tq < mT; ++tq) {
+                    const double x = p.Tq[tq];
+                    double r = nanv;
+                    if (cn > 0) {
+                        while (jc + 1 < cn && cx(jc + 1) <= x) ++jc;          // Tq ascending (checked: tt.unsorted)
+                        r = eval_method(METHOD, cx, cy, csr, cn, jc, x);
+                    }
+                    outb[(int64_t)tq * mK + lane] = r;
+                }
+            }
+        }
+        if (act && all_ok) dense_maturity_pass<METHOD, true, false, false, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp);
+        if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
+      }
+    }
+}
+
+#ifndef IVS_DIAG_MINIMAL
+// Second pass behind the dense / row-pass kernel for uniform 64 x 16 batches: returns true when launched.
+inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
+    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) return false;
+    if (p.k_off || p.nK != DK || p.nT != DT || p.mK > 64 || p.mT > D_MAX_MT) return false;
+    if (p.t_stride != 0 || p.tq_stride != 0 || !p.tqs) return false;
+    const size_t lds = masked_lds_bytes();
+    int64_t grid = (int64_t)cx.num_cu * 8;
+    const int64_t work = (p.B + 63) / 64;
+    if (grid > work) grid = work;
+    if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_masked_kernel<IVS_CUBIC>), dim3((unsigned)grid), dim3(64), lds, cx.st, p);
+    else hipLaunchKernelGGL((surface_masked_kernel<IVS_CUBICSPLINE>), dim3((unsigned)grid), dim3(64), lds, cx.st, p);
+    return true;
+}
+#endif
+
+}  // namespace ivs

@@ -20,6 +20,7 @@
 // would recompute the slopes per block), 4..16 maturities; everything else stays on the one-pass kernels.
 #pragma once
 #include "ivs_surface_dense_var2.hpp"
+#include "ivs_surface_masked.hpp"
 
 namespace ivs {
 
@@ -511,7 +512,10 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
 #endif
     }
     if (hipGetLastError() != hipSuccess) return -1;
-    launch_surface_generic<true>(p, cx);     // redo pass for tagged surfaces (cheap when none are)
+#ifndef IVS_DIAG_MINIMAL
+    if (fixed64) launch_surface_masked(p, cx);   // tagged surfaces (missing quotes): the masked fast pass first ...
+#endif
+    launch_surface_generic<true>(p, cx);     // ... then the generic kernel for whatever is still tagged (cheap when nothing is)
     return 1;
 }
 
