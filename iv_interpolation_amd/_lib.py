@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libivs.so")
 LINEAR, CUBIC, CUBICSPLINE, SLINEAR = 0, 1, 2, 3
 ST_OK, ST_TOO_FEW_KNOTS, ST_BAD_SHAPE, ST_ILL_CONDITIONED = 0, 1, 2, 4
 FLAG_FORCE_GENERIC = 1
+FLAG_ONE_PASS = 2          # IVS_FLAG_ONE_PASS: skip the row-pass kernels (testing / A-B timing)
 
 
 def flag_map_groups(n: int) -> int:

@@ -70,7 +70,7 @@ def surface_workspace(B: int, ragged: bool, device=None):
 
 def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: Optional[int] = None,
                   n_maturities: Optional[int] = None, out=None, status=None, stream=None,
-                  force_generic: bool = False, workspace=None, map_groups: int = 0):
+                  force_generic: bool = False, workspace=None, map_groups: int = 0, one_pass: bool = False):
     """Interpolate a batch of (strike x maturity) surfaces on the current device.
 
     Uniform: K [B,nK] or [nK] (shared), sigma [B,nT,nK].  Ragged: K flat [total], sigma flat
@@ -114,7 +114,8 @@ def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: O
         workspace = torch.empty(need, dtype=torch.uint8, device=sigma.device)
     elif workspace.numel() * workspace.element_size() < need or not workspace.is_cuda:
         raise ValueError(f"workspace too small: {workspace.numel() * workspace.element_size()} < {need} bytes")
-    flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | _lib.flag_map_groups(map_groups)
+    flags = ((_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (_lib.FLAG_ONE_PASS if one_pass else 0)
+             | _lib.flag_map_groups(map_groups))
     rc = lib.ivs_surface_batch_f64(_ptr(K), _ptr(k_off), k_stride, nK, _ptr(T), t_stride, nT, _ptr(sigma), B,
                                    _ptr(Kq), kq_stride, mK, _ptr(Tq), tq_stride, mT, _ptr(out), _ptr(status),
                                    code, flags, _ptr(workspace), workspace.numel() * workspace.element_size(),

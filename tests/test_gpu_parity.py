@@ -146,6 +146,30 @@ def test_config2_10k_surfaces_vs_oracle(method, force_generic):
     close(got, ref, method, f"config2 {method} [{kern}]")
 
 
+@pytest.mark.parametrize("method", ["cubic", "cubicspline"])
+def test_one_pass_kernels_behind_the_flag(method):
+    """The row-pass kernels serve cubic / cubicspline with shared maturities and <= 64 output strikes; the one-pass dense,
+    variable-shape and two-wavefront kernels keep serving every other call (and IVS_FLAG_ONE_PASS selects them for A/B
+    timing): the same batches through both families against the oracle."""
+    from iv_interpolation_amd import engine, synth
+    Kq, Tq = synth.query_grids(64, 16)
+    d = synth.numpy_batch(2000, 64, 16, seed=synth.BASE_SEED + 40)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    for one_pass, want in ((False, "surface_pass_kernel"), (True, "surface_dense_kernel")):
+        out, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method, one_pass=one_pass)
+        assert engine.last_kernel().startswith(want), engine.last_kernel()
+        assert np.array_equal(st.cpu().numpy(), rst)
+        close(out.cpu().numpy(), ref, method, f"{want} {method}")
+    r = synth.numpy_ragged_batch(600, 16, 8, 128, seed=41)
+    ref, rst = O.surface_batch(r["K"], r["T"], r["sigma"], Kq, Tq, METHODS[method], k_off=r["k_off"])
+    for one_pass, want in ((False, "surface_pass_var_kernel"), (True, "surface_dense_var_kernel")):
+        out, st = engine.surface_batch(dev(r["K"]), dev(r["T"]), dev(r["sigma"]), dev(Kq), dev(Tq), method, k_off=dev(r["k_off"]),
+                                       nK_max=r["nK_max"], n_maturities=16, one_pass=one_pass)
+        assert engine.last_kernel().startswith(want), engine.last_kernel()
+        assert np.array_equal(st.cpu().numpy(), rst)
+        close(out.cpu().numpy(), ref, method, f"{want} ragged {method}")
+
+
 @pytest.mark.parametrize("method", ["linear", "cubic"])
 def test_config4_dense_output_grid(method):
     from iv_interpolation_amd import synth
@@ -481,6 +505,36 @@ def test_interp1d_wavefront_solve_block_boundaries(method):
             scale = np.nanmax(np.abs(ref[c, sl])) if np.isfinite(ref[c, sl]).any() else 1.0
             err = np.nanmax(np.abs(got[c, sl] - ref[c, sl])) if np.isfinite(ref[c, sl]).any() else 0.0
             assert err <= 1e-11 * max(scale, 1.0), (method, n, c, err, scale)
+
+
+@pytest.mark.parametrize("power,bound", [(2, 5e-12), (4, 5e-10), (8, 5e-6)])
+def test_ill_conditioned_strike_grids_are_bounded(power, bound):
+    """Knot spacings with dx ratios ~4e2 / 1.6e5 / 2.5e10 (u^2 / u^4 / u^8 spacing of strikes AND maturities): the
+    scan-based factorisations (row-pass / dense kernels) and the serial Thomas recurrence (generic kernel) against the
+    oracle, error relative to the surface's largest value.  Stated bounds per grid; measured (MI355X): row-pass / dense
+    1.8e-13 / 8e-12 / 1.8e-7, generic 7e-14 / 4e-12 / 5e-7 -- the serial recurrence is no more accurate than the scans
+    (the error is the conditioning of the not-a-knot system itself: scipy's own CubicSpline and interp1d routes differ by
+    3e-11 at a ratio of 1e5), which is why there is no guard routing such grids to the serial solve."""
+    from iv_interpolation_amd import engine
+    r = np.random.default_rng(0)
+    B, nK, nT = 200, 64, 16
+    for _ in range({2: 0, 4: 1, 8: 2}[power]):      # the probe's random stream (tests/bench/conditioning_probe.py)
+        r.uniform(0.05, 1, (400, nK)); r.uniform(0.05, 1, nT); r.uniform(0.2, 1.0, (400, nT, nK))
+    K = np.cumsum(r.uniform(0.05, 1, (B, nK)) ** power, axis=1); K = 0.7 + 0.6 * (K - K[:, :1]) / (K[:, -1:] - K[:, :1])
+    T = np.cumsum(r.uniform(0.05, 1, nT) ** power); T = 0.01 + 1.4 * (T - T[0]) / (T[-1] - T[0])
+    sig = r.uniform(0.2, 1.0, (B, nT, nK))
+    Kq = np.linspace(0.701, 1.299, 64); Tq = np.linspace(0.011, 1.409, 16)
+    ref, _ = O.surface_batch(K, T, sig, Kq, Tq, O.CUBIC)
+    scale = np.nanmax(np.abs(ref), axis=(1, 2), keepdims=True)
+    kernels = set()
+    for kw in (dict(), dict(one_pass=True), dict(force_generic=True)):
+        out, st = engine.surface_batch(dev(K), dev(T), dev(sig), dev(Kq), dev(Tq), "cubic", **kw)
+        kernels.add(engine.last_kernel())
+        got = out.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (power, kw)
+        err = float(np.nanmax(np.abs(got - ref) / scale))
+        assert err <= bound, (power, kw, engine.last_kernel(), err)
+    assert len(kernels) == 3, kernels                 # row-pass, one-pass dense and generic kernels were all exercised
 
 
 def test_interpolate_frame_against_reference_goldens_on_gpu():
