@@ -62,19 +62,21 @@ def _chan_finish(values: np.ndarray, kind: str, dtype):
 
 
 class HipBackend:
-    """Moves packed host columns to the current HIP device and calls the kernels."""
+    """Moves packed host columns to the current HIP device and calls the kernels.  Uploads of the (pageable, temporary)
+    packed arrays are ordinary blocking copies: an asynchronous copy would outlive the temporary it reads from.  Results
+    come back through pinned buffers with asynchronous copies behind the kernels (frame_columns)."""
 
     def interp1d_batch(self, xk, yk, knot_off, q_off, total_q, code):
         from . import engine
         torch = engine.require_device()
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         out, st = engine.interp1d_batch(d(xk), d(yk), d(knot_off), d(q_off), int(total_q), code)
         return out.cpu().numpy(), st.cpu().numpy()
 
     def ffill_index_batch(self, src_pos, src_off, valid, q_off, total_q):
         from . import engine
         torch = engine.require_device()
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         return engine.ffill_index_batch(d(src_pos), d(src_off), d(valid), d(q_off), int(total_q)).cpu().numpy()
 
     def interp1d_greeks_batch(self, xk, yk, knot_off, q_off, total_q, code, src_pos, gvalid, strike_src, rate_src, put_src):
@@ -82,7 +84,7 @@ class HipBackend:
         on the device and consumed by the eval kernel without leaving it."""
         from . import engine
         torch = engine.require_device()
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         ko, qo = d(knot_off), d(q_off)
         fidx = engine.ffill_index_batch(d(src_pos), ko, d(gvalid), qo, int(total_q))
         out, st, gr = engine.interp1d_greeks_batch(d(xk), d(yk), ko, qo, int(total_q), code, (0, 1, 2), fidx, (0, 1, 2),
@@ -98,7 +100,7 @@ class HipBackend:
         through asynchronous copies behind the kernels (one synchronisation); the NumPy arrays returned are views of it."""
         from . import engine
         torch = engine.require_device()
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)  # noqa: E731
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         ko, qo = d(src_off), d(q_off)
         pos_d = d(pos)
         fidx = engine.ffill_index_batch(pos_d, ko, d(valid), qo, int(total_q)) if valid.shape[0] else None
