@@ -22,53 +22,67 @@
 #include "ivs_surface_dense_var2.hpp"
 #include "ivs_surface_masked.hpp"
 
+#ifndef IVS_PASS_SL
+#define IVS_PASS_SL 8      // knots per segment of the uniform 64 x 16 kernel (8: 12 workgroups / CU, 4: 16)
+#endif
+
+#ifndef IVS_PASS_PFP4
+#define IVS_PASS_PFP4 2
+#endif
 namespace ivs {
 
-template <int NKB>
+template <int NKB, int SL = 8>
 struct PassGeom {
-    static constexpr int NSEG = 8 * NKB;           // segments of 8 knots per row
+    static constexpr int NSEG = 64 * NKB / SL;     // segments of SL (8 or 4) knots per row
     static constexpr int RP = 64 / NSEG;           // rows per pass
     static constexpr int NPASS = DT / RP;
     static constexpr int KCAP = 64 * NKB;
     static constexpr int RS = KCAP + 2;            // plane row stride (doubles)
-    static constexpr int PLANE = RP * RS;          // the two spare slots behind a row are read as y_{kb+8} of its last segment
-    static constexpr int TS = 10;                  // table segment stride (8 entries + 2 spare)
+    static constexpr int PLANE = RP * RS;          // the two spare slots behind a row are read as y_{kb+SL} of its last segment
+    static constexpr int TS = SL + 2;              // table segment stride (SL entries + 2 spare)
     static constexpr int TN = NSEG * TS;           // one table
-    static constexpr int NSCAN = NKB == 1 ? 3 : 4; // carry scan steps (shift 1, 2, 4[, 8])
+    static constexpr int NSCAN = NSEG == 8 ? 3 : 4; // carry scan steps (shift 1, 2, 4[, 8])
+    static_assert(SL == 8 || (SL == 4 && NKB == 1), "segment length");
+    static_assert(NSEG == 8 || NSEG == 16, "a row's segments live in one DPP row");
 };
-template <int NKB, bool VAR>
+template <int NKB, bool VAR, int SL = 8>
 __host__ __device__ constexpr size_t pass_lds_bytes() {
-    using G = PassGeom<NKB>;
+    using G = PassGeom<NKB, SL>;
     // Y, S planes; AL CP PP QQ PI PSI [PM] tables; Ksh
     return (size_t)(2 * G::PLANE + (VAR ? 7 : 6) * G::TN + G::KCAP) * 8;
 }
 
-__device__ __forceinline__ int p_tix(int k) { return (k >> 3) * 10 + (k & 7); }
-__device__ __forceinline__ int p_swz(int k) { return k ^ (((k >> 4) & 3) << 1); }     // S plane: slot c of segment s at c ^ (s >> 1)
+template <int SL> __device__ __forceinline__ int p_tix(int k) { return (k / SL) * (SL + 2) + (k % SL); }
+// S plane, 8-knot segments: 16-byte slot c of segment s sits at c ^ (s >> 1) (conflict-free b128 writes); 4-knot segments
+// need no swizzle (the odd row stride already interleaves the two rows of a 16-lane write group)
+template <int SL> __device__ __forceinline__ int p_swz(int k) { return SL == 8 ? k ^ (((k >> 4) & 3) << 1) : k; }
 
-// inclusive prefix / suffix products within aligned groups of 8 lanes (two groups per DPP row: a shifted value that
+// inclusive prefix / suffix products within aligned groups of SL lanes (several groups per DPP row: a shifted value that
 // comes from the neighbouring group is replaced by 1.0)
-__device__ __forceinline__ double seg8_prefix_prod(double v, int lane) {
-    const int i = lane & 7;
+template <int SL>
+__device__ __forceinline__ double seg_prefix_prod(double v, int lane) {
+    const int i = lane & (SL - 1);
     double t = dpp_f64<DPP_ROW_SHR(1)>(1.0, v); v *= i >= 1 ? t : 1.0;
     t = dpp_f64<DPP_ROW_SHR(2)>(1.0, v); v *= i >= 2 ? t : 1.0;
-    t = dpp_f64<DPP_ROW_SHR(4)>(1.0, v); v *= i >= 4 ? t : 1.0;
+    if (SL > 4) { t = dpp_f64<DPP_ROW_SHR(4)>(1.0, v); v *= i >= 4 ? t : 1.0; }
     return v;
 }
-__device__ __forceinline__ double seg8_suffix_prod(double v, int lane) {
-    const int i = lane & 7;
-    double t = dpp_f64<DPP_ROW_SHL(1)>(1.0, v); v *= i <= 6 ? t : 1.0;
-    t = dpp_f64<DPP_ROW_SHL(2)>(1.0, v); v *= i <= 5 ? t : 1.0;
-    t = dpp_f64<DPP_ROW_SHL(4)>(1.0, v); v *= i <= 3 ? t : 1.0;
+template <int SL>
+__device__ __forceinline__ double seg_suffix_prod(double v, int lane) {
+    const int i = lane & (SL - 1);
+    double t = dpp_f64<DPP_ROW_SHL(1)>(1.0, v); v *= i <= SL - 2 ? t : 1.0;
+    t = dpp_f64<DPP_ROW_SHL(2)>(1.0, v); v *= i <= SL - 3 ? t : 1.0;
+    if (SL > 4) { t = dpp_f64<DPP_ROW_SHL(4)>(1.0, v); v *= i <= 3 ? t : 1.0; }
     return v;
 }
 
 // K-phase: factorisation tables of the not-a-knot system on n knots (n = KCAP when !VAR) at p_tix(k), the segment
 // products P_j = prod(-AL) / Q_j = prod(-CP) of every 8-knot segment, and from them the multipliers of the carry scans
 // (see pass_sweeps).  Ends with the tables visible to every lane.
-template <int NKB, bool VAR>
+template <int NKB, bool VAR, int SL = 8>
 __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int lane, double* TB) {
-    using G = PassGeom<NKB>;
+    using G = PassGeom<NKB, SL>;
+    constexpr int TS = G::TS;
     constexpr int TN = G::TN, NSEG = G::NSEG;
     double* AL = TB; double* CP = TB + TN; double* PP = TB + 2 * TN; double* QQ = TB + 3 * TN;
     double* PI = TB + 4 * TN; double* PSI = TB + 5 * TN; double* PM = TB + 6 * TN;
@@ -128,16 +142,16 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
             pp = 3.0 * dxc * rdx_prev * rw;                      // * dy_{i-1}
             qq = 3.0 * dxm * rdxc * rw;                          // * dy_i
         }
-        const double pi = seg8_prefix_prod(in ? -al : 1.0, lane);
-        const double psi = seg8_suffix_prod(in ? -cp : 1.0, lane);
+        const double pi = seg_prefix_prod<SL>(in ? -al : 1.0, lane);
+        const double psi = seg_suffix_prod<SL>(in ? -cp : 1.0, lane);
         {   // beyond n the NEUTRAL row (AL = -1, everything else 0): the forward sweep holds its value, the last system
             // row's CP = 0 cuts the backward recurrence off from whatever lies to its right (see factor_tables_var)
-            const int kl = p_tix(ir);
+            const int kl = p_tix<SL>(ir);
             AL[kl] = in ? al : -1.0; CP[kl] = in ? cp : 0.0; PP[kl] = in ? pp : 0.0; QQ[kl] = in ? qq : 0.0;
             if (VAR) PM[kl] = in ? pm : 0.0;
             PI[kl] = pi; PSI[kl] = psi;
-            if ((lane & 7) == 7) PI[(ir >> 3) * 10 + 8] = pi;                  // P_j: product of (-AL) over segment j (spare slot)
-            if ((lane & 7) == 0) PSI[(ir >> 3) * 10 + 8] = in ? psi : 0.0;     // Q_j: product of (-CP)
+            if ((lane & (SL - 1)) == SL - 1) PI[(ir / SL) * TS + SL] = pi;               // P_j: product of (-AL) over segment j (spare slot)
+            if ((lane & (SL - 1)) == 0) PSI[(ir / SL) * TS + SL] = in ? psi : 0.0;       // Q_j: product of (-CP)
         }
         if (blk + 1 < NKB) {
             c00 = readlane_f64(p00, 63); c01 = readlane_f64(p01, 63); c10 = readlane_f64(p10, 63); c11 = readlane_f64(p11, 63);
@@ -149,7 +163,7 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
         // P_j P_{j-1} .. P_{j-s+1}; 0 where no such segment exists (it also silences the DPP sources of the neighbouring
         // row when two rows share a DPP row).  Backward: Q_j .. Q_{j+s-1} and the segment to the right.
         const int j = lane < NSEG ? lane : NSEG - 1;
-        double pw = lane < NSEG ? PI[j * 10 + 8] : 1.0, qw = lane < NSEG ? PSI[j * 10 + 8] : 1.0;
+        double pw = lane < NSEG ? PI[j * TS + SL] : 1.0, qw = lane < NSEG ? PSI[j * TS + SL] : 1.0;
         double fm[4], bm[4];
 #pragma unroll
         for (int s = 0; s < G::NSCAN; ++s) {
@@ -159,29 +173,29 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
             if (s == 1) { pw *= dpp_f64<DPP_ROW_SHR(2)>(1.0, pw); qw *= dpp_f64<DPP_ROW_SHL(2)>(1.0, qw); }
             if (s == 2) { pw *= dpp_f64<DPP_ROW_SHR(4)>(1.0, pw); qw *= dpp_f64<DPP_ROW_SHL(4)>(1.0, qw); }
         }
-        if (lane < NSEG) {      // spare slots 8, 9 of segment j in the AL / CP / PP / QQ tables
-            AL[j * 10 + 8] = fm[0]; AL[j * 10 + 9] = fm[1]; CP[j * 10 + 8] = fm[2];
-            PP[j * 10 + 8] = bm[0]; PP[j * 10 + 9] = bm[1]; QQ[j * 10 + 8] = bm[2];
-            if (NKB > 1) { CP[j * 10 + 9] = fm[3]; QQ[j * 10 + 9] = bm[3]; }
+        if (lane < NSEG) {      // the two spare slots of segment j in the AL / CP / PP / QQ tables
+            AL[j * TS + SL] = fm[0]; AL[j * TS + SL + 1] = fm[1]; CP[j * TS + SL] = fm[2];
+            PP[j * TS + SL] = bm[0]; PP[j * TS + SL + 1] = bm[1]; QQ[j * TS + SL] = bm[2];
+            if (NSEG > 8) { CP[j * TS + SL + 1] = fm[3]; QQ[j * TS + SL + 1] = bm[3]; }
         }
     }
     __syncthreads();
 }
 
 // One pass: slopes of the RP rows staged in Yp -> Sp.  All 64 lanes; no barrier inside (the caller brackets it).
-template <int NKB, bool VAR>
+template <int NKB, bool VAR, int SL = 8>
 __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const double* TB, int lane) {
-    using G = PassGeom<NKB>;
-    constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS;
+    using G = PassGeom<NKB, SL>;
+    constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS, TS = G::TS;
     const double* AL = TB; const double* CP = TB + TN; const double* PP = TB + 2 * TN; const double* QQ = TB + 3 * TN;
     const double* PI = TB + 4 * TN; const double* PSI = TB + 5 * TN; const double* PM = TB + 6 * TN;
     const int tl = lane / NSEG, seg = lane % NSEG;
-    const int kb = seg * 8, tb = seg * 10;
+    const int kb = seg * SL, tb = seg * TS;
     const bool s_first = seg == 0, s_last = seg == NSEG - 1;
     const double* yr = Yp + tl * RS + kb;
-    double y[11];                                   // y[j] = y_{kb + j - 2}
+    double y[SL + 3];                                   // y[j] = y_{kb + j - 2}
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < SL / 2; ++c) {
         const double2 v = *reinterpret_cast<const double2*>(yr + 2 * c);
         y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
     }
@@ -189,12 +203,12 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
         const double2 v = *reinterpret_cast<const double2*>(s_first ? yr : yr - 2);
         y[0] = v.x; y[1] = v.y;
     }
-    y[10] = yr[8];                                  // last segment: the spare slot behind the row (kept finite)
+    y[SL + 2] = yr[SL];                                 // last segment: the spare slot behind the row (kept finite)
     auto tab2 = [&](const double* T, int m) { return *reinterpret_cast<const double2*>(T + tb + m); };   // entries m, m+1
-    double d[8];
+    double d[SL];
     double prev = 0.0;
 #pragma unroll
-    for (int mm = 0; mm < 8; mm += 2) {
+    for (int mm = 0; mm < SL; mm += 2) {
         const double2 tpp = tab2(PP, mm), tqq = tab2(QQ, mm), tal = tab2(AL, mm);
         double2 tpm = double2{0.0, 0.0};
         if (VAR) tpm = tab2(PM, mm);
@@ -203,28 +217,28 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
             const int m = mm + u;
             double dM = y[m + 1] - y[m], dA = y[m + 2] - y[m + 1], dB = y[m + 3] - y[m + 2];   // dy_{i-2}, dy_{i-1}, dy_i
             if (m == 0) { const double e = y[4] - y[3]; dA = s_first ? dB : dA; dB = s_first ? e : dB; }      // row 0: (dy_0, dy_1)
-            if (!VAR && m == 7) { dB = s_last ? dA : dB; dA = s_last ? dM : dA; }                             // row n-1: (dy_{n-3}, dy_{n-2})
+            if (!VAR && m == SL - 1) { dB = s_last ? dA : dB; dA = s_last ? dM : dA; }                             // row n-1: (dy_{n-3}, dy_{n-2})
             double r = (u ? tpp.y : tpp.x) * dA + (u ? tqq.y : tqq.x) * dB;
             if (VAR) r += (u ? tpm.y : tpm.x) * dM;
             prev = r - (u ? tal.y : tal.x) * prev;
             d[m] = prev;
         }
-        if (mm == 2) __builtin_amdgcn_sched_barrier(0);
+        if (SL == 8 && mm == 2) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- forward carries: tot_j = E_j + P_j tot_{j-1} over the segments of the row, Kogge-Stone on the E part
-    const double2 fm01 = *reinterpret_cast<const double2*>(AL + tb + 8);
-    const double2 fm23 = *reinterpret_cast<const double2*>(CP + tb + 8);
+    const double2 fm01 = *reinterpret_cast<const double2*>(AL + tb + SL);
+    const double2 fm23 = *reinterpret_cast<const double2*>(CP + tb + SL);
     double e = prev;
     e = __builtin_fma(fm01.x, dpp0_f64<DPP_ROW_SHR(1)>(e), e);
     e = __builtin_fma(fm01.y, dpp0_f64<DPP_ROW_SHR(2)>(e), e);
     e = __builtin_fma(fm23.x, dpp0_f64<DPP_ROW_SHR(4)>(e), e);
-    if (NKB > 1) e = __builtin_fma(fm23.y, dpp0_f64<DPP_ROW_SHR(8)>(e), e);
+    if (NSEG > 8) e = __builtin_fma(fm23.y, dpp0_f64<DPP_ROW_SHR(8)>(e), e);
     double din = dpp0_f64<DPP_ROW_SHR(1)>(e);
     din = s_first ? 0.0 : din;
     // ---- local backward sweep with the forward fix-up folded in
     double nxt = 0.0;
 #pragma unroll
-    for (int mm = 6; mm >= 0; mm -= 2) {
+    for (int mm = SL - 2; mm >= 0; mm -= 2) {
         const double2 tpi = tab2(PI, mm), tcp = tab2(CP, mm);
 #pragma unroll
         for (int u = 1; u >= 0; --u) {
@@ -233,22 +247,22 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
             nxt = dp - (u ? tcp.y : tcp.x) * nxt;
             d[m] = nxt;
         }
-        if (mm == 4) __builtin_amdgcn_sched_barrier(0);
+        if (SL == 8 && mm == 4) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- backward carries: first_j = F_j + Q_j first_{j+1}
-    const double2 bm01 = *reinterpret_cast<const double2*>(PP + tb + 8);
-    const double2 bm23 = *reinterpret_cast<const double2*>(QQ + tb + 8);
+    const double2 bm01 = *reinterpret_cast<const double2*>(PP + tb + SL);
+    const double2 bm23 = *reinterpret_cast<const double2*>(QQ + tb + SL);
     double f = nxt;
     f = __builtin_fma(bm01.x, dpp0_f64<DPP_ROW_SHL(1)>(f), f);
     f = __builtin_fma(bm01.y, dpp0_f64<DPP_ROW_SHL(2)>(f), f);
     f = __builtin_fma(bm23.x, dpp0_f64<DPP_ROW_SHL(4)>(f), f);
-    if (NKB > 1) f = __builtin_fma(bm23.y, dpp0_f64<DPP_ROW_SHL(8)>(f), f);
+    if (NSEG > 8) f = __builtin_fma(bm23.y, dpp0_f64<DPP_ROW_SHL(8)>(f), f);
     double sin_ = dpp0_f64<DPP_ROW_SHL(1)>(f);
     sin_ = s_last ? 0.0 : sin_;
     double* srow = Sp + tl * RS + kb;
-    const int sx = (seg >> 1) & 3;
+    const int sx = SL == 8 ? (seg >> 1) & 3 : 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < SL / 2; ++c) {
         const double2 tps = tab2(PSI, 2 * c);
         double2 v;
         v.x = d[2 * c] + tps.x * sin_; v.y = d[2 * c + 1] + tps.y * sin_;
@@ -259,12 +273,13 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
 // VAR = false: uniform batch of 64 x 16 surfaces (BASELINE configs 2/3), surface -> workgroup mapping as surface_dense_kernel.
 // VAR = true : work list of a size class (n <= 64 * NKB strikes per surface, run-time maturity count), or a uniform
 //              batch with nK != 64.
-template <int METHOD, int NKB, bool VAR>
-__global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, VarList list) {
-    using G = PassGeom<NKB>;
+template <int METHOD, int NKB, bool VAR, int SL = 8>
+__global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(SurfaceParams p, VarList list) {
+    using G = PassGeom<NKB, SL>;
     constexpr int RP = G::RP, NPASS = G::NPASS, KCAP = G::KCAP, RS = G::RS, TN = G::TN;
-    constexpr int PFP = NKB == 1 ? NPASS : 1;        // passes per prefetch group (64 strikes: the whole surface)
-    constexpr int NPRE = PFP * RP * NKB;             // doubles per lane and group
+    constexpr int PFP = NKB > 1 ? 1 : (SL == 4 ? IVS_PASS_PFP4 : NPASS);   // passes in flight per lane (8-knot segments, 64 strikes: a whole surface)
+    constexpr int PPL = RP * NKB;                    // doubles per lane and pass
+    static_assert(NPASS % PFP == 0, "prefetch slots rotate with the passes");
     static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot methods only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -308,27 +323,28 @@ __global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, Va
         n = p.nK; koff = i * p.k_stride; return i;
     };
 
-    // ---- prefetch registers: group g of a surface = its passes g*PFP .. g*PFP + PFP - 1
-    double pre[NPRE], pre_k[NKB];
-    auto issue_group = [&](int64_t b, int64_t ko, int nn, int g) {
+    // ---- prefetch registers: pass ps of a surface lands in slot ps % PFP, requested PFP passes ahead of its staging
+    double pre[PFP * PPL], pre_k[NKB];
+    auto issue_pass = [&](int64_t b, int64_t ko, int nn, int ps) {
+        const int slot = ps % PFP;
         if (!VAR) {      // chunk c of the surface = 16 B at c*1024 + lane*16: rows 2c + (lane >> 5), strikes 2(lane & 31), +1
             const double2* s2 = reinterpret_cast<const double2*>(p.sigma + b * (int64_t)(DT * DK));
 #pragma unroll
-            for (int c = 0; c < NPRE / 2; ++c) {
-                const double2 v = s2[(g * (NPRE / 2) + c) * 64 + lane];
-                pre[2 * c] = v.x; pre[2 * c + 1] = v.y;
+            for (int c = 0; c < RP / 2; ++c) {
+                const double2 v = s2[(ps * (RP / 2) + c) * 64 + lane];
+                pre[slot * RP + 2 * c] = v.x; pre[slot * RP + 2 * c + 1] = v.y;
             }
         } else {
             const double* sb = p.k_off ? p.sigma + (int64_t)nT * ko : p.sigma + b * (int64_t)nT * p.nK;
 #pragma unroll
-            for (int r = 0; r < PFP * RP; ++r)
+            for (int r = 0; r < RP; ++r)
 #pragma unroll
                 for (int blk = 0; blk < NKB; ++blk) {
-                    const int t = g * PFP * RP + r, k = blk * 64 + lane;
-                    pre[r * NKB + blk] = (t < nT && k < nn) ? sb[(int64_t)t * nn + k] : 0.0;      // rows beyond nT: zeros
+                    const int t = ps * RP + r, k = blk * 64 + lane;
+                    pre[(slot * RP + r) * NKB + blk] = (t < nT && k < nn) ? sb[(int64_t)t * nn + k] : 0.0;      // rows beyond nT: zeros
                 }
         }
-        if (g == 0) {
+        if (ps == 0) {
 #pragma unroll
             for (int blk = 0; blk < NKB; ++blk) {
                 const int k = blk * 64 + lane;
@@ -339,7 +355,11 @@ __global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, Va
 
     int n = KCAP, n_next = KCAP;
     int64_t koff = 0, koff_next = 0, b = 0, b_next = 0;
-    if (it < it_end) { b = at(it, n, koff); issue_group(b, koff, n, 0); }
+    if (it < it_end) {
+        b = at(it, n, koff);
+#pragma unroll
+        for (int ps = 0; ps < PFP; ++ps) issue_pass(b, koff, n, ps);
+    }
 
     while (it < it_end) {
         double* outb = p.out + b * (int64_t)mT * mK;
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, Va
         double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            const int g = ps / PFP, slot = ps % PFP;
+            const int slot = ps % PFP;
             __syncthreads();                                   // the previous pass's gathers are done with the planes
             // ---- stage pass ps; any non-finite quote (NaN = missing, or an infinity) sends the surface to the generic kernel
             double acc = 0.0;
@@ -364,10 +384,8 @@ __global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, Va
                     double2 v; v.x = pre[slot * RP + 2 * c]; v.y = pre[slot * RP + 2 * c + 1];
                     *reinterpret_cast<double2*>(&Yp[tl * RS + k]) = v;
                 }
-                if (ps == 0) {
 #pragma unroll
-                    for (int c = 0; c < NPRE; ++c) acc = __builtin_fma(pre[c], 0.0, acc);
-                }
+                for (int c = 0; c < RP; ++c) acc = __builtin_fma(pre[slot * RP + c], 0.0, acc);
             } else {
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
@@ -382,15 +400,16 @@ __global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, Va
 #pragma unroll
                 for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
             }
-            if (VAR || ps == 0) ok = ok && __ballot(acc != 0.0) == 0ull;
-            if (slot == PFP - 1) {                             // the group's registers are free: request the next group
-                if (g + 1 < NPASS / PFP) issue_group(b, koff, n, g + 1);
-                else if (more) issue_group(b_next, koff_next, n_next, 0);
+            ok = ok && __ballot(acc != 0.0) == 0ull;
+            {                                                  // the slot's registers are free: request the pass PFP ahead
+                const int nx = ps + PFP;
+                if (nx < NPASS) issue_pass(b, koff, n, nx);
+                else if (more) issue_pass(b_next, koff_next, n_next, nx - NPASS);
             }
             __syncthreads();
             if (ok) {
                 if (ps == 0) {
-                    if (ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR>(Ksh, n, lane, TB);
+                    if (ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB);
                     // ---- strike search + Hermite weights of this lane's output strike (once per surface)
 #pragma unroll
                     for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
@@ -407,10 +426,10 @@ __global__ __launch_bounds__(64, 3) void surface_pass_kernel(SurfaceParams p, Va
                     w2 = u * omt * omt;
                     w3 = u * t * (t - 1.0);
                 }
-                if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR>(Yp, Sp, TB, lane);
+                if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane);
                 __syncthreads();
                 // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
-                const int o0 = jj, o1 = jj + 1, q0 = p_swz(jj), q1 = p_swz(jj + 1);
+                const int o0 = jj, o1 = jj + 1, q0 = p_swz<SL>(jj), q1 = p_swz<SL>(jj + 1);
                 if (ABL == 2 || ABL == 6) {
 #pragma unroll
                     for (int r = 0; r < RP; ++r) z[ps * RP + r] = Yp[r * RS + lane] + w0;
@@ -460,9 +479,9 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
     if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
     p.tqs = tq;
-    auto grid_for = [&](size_t lds, int64_t work) {
+    auto grid_for = [&](size_t lds, int64_t work, int wg_cap = 12) {
         int per_cu = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));     // LDS is granted in 1280-byte granules
-        per_cu = per_cu > 12 ? 12 : (per_cu < 1 ? 1 : per_cu);                 // 3 wavefronts per SIMD (168 VGPRs)
+        per_cu = per_cu > wg_cap ? wg_cap : (per_cu < 1 ? 1 : per_cu);         // 3 wavefronts per SIMD (168 VGPRs); 4 with 4-knot segments (128)
 #ifdef IVS_PASS_PER_CU
         per_cu = IVS_PASS_PER_CU;                                              // diagnostic builds (tools/pass_api.hip)
 #endif
@@ -471,12 +490,13 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     };
     const VarList none{nullptr, nullptr};
     if (fixed64) {
-        const size_t lds = pass_lds_bytes<1, false>();
-        const int64_t grid = grid_for(lds, p.B);
+        constexpr int FSL = IVS_PASS_SL;
+        const size_t lds = pass_lds_bytes<1, false, FSL>();
+        const int64_t grid = grid_for(lds, p.B, FSL == 4 ? 16 : 12);
         p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);
-        if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, false>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
+        if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, false, FSL>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
 #ifndef IVS_DIAG_MINIMAL
-        else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, false>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
+        else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, false, FSL>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
 #endif
         *name = p.method == IVS_CUBIC ? "surface_pass_kernel<cubic>" : "surface_pass_kernel<cubicspline>";
     } else {
