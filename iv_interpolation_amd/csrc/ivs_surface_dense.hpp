@@ -1172,6 +1172,7 @@ inline int dense_map_groups(int64_t grid, int64_t B, int forced) {
 }
 
 #ifndef IVS_DIAG_MINIMAL      // diagnostic builds (tools/pass_api.hip) skip the launchers that instantiate every kernel
+inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx);      // ivs_surface_masked.hpp
 // Dense dispatch.  Returns 1 if dispatched (dense kernel + filtered generic redo pass), 0 if the
 // shape is not covered by a dense kernel.
 inline int launch_surface_dense(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name,
@@ -1229,7 +1230,8 @@ inline int launch_surface_dense(const SurfaceParams& p_in, const LaunchCtx& cx, 
     }
 #undef IVS_DENSE_CASE
     if (hipGetLastError() != hipSuccess) return -1;
-    launch_surface_generic<true>(p, cx);     // redo pass for tagged surfaces (cheap when none are)
+    launch_surface_masked(p, cx);            // tagged surfaces (missing quotes): compaction kernel first (shared T / Tq only) ...
+    launch_surface_generic<true>(p, cx);     // ... then whatever is still tagged (cheap when nothing is)
     return 1;
 }
 

@@ -1,4 +1,4 @@
-// Surfaces with MISSING quotes (NaN in sigma), 64 strikes x 16 maturities, not-a-knot methods: the fast second pass.
+// Surfaces with MISSING quotes (NaN in sigma), 64 strikes x 16 maturities: the fast second pass.
 //
 // A missing quote changes the KNOT SET of its row, so every row has its own tridiagonal system -- the shared
 // factorisation of the dense kernels does not apply -- and until now any NaN sent the surface to the correctness-first
@@ -19,8 +19,11 @@
 //     Surfaces with a row of fewer than 4 quotes, a column with too few values or more than 8 masked columns keep
 //     their "redo" tag and fall through to the generic kernel (third launch, cheap when nothing is left).
 // LDS: two planes [16][66] + two byte tables = 19.5 KB = 8 wavefronts per CU.
-// Scope: uniform 64 x 16 batches, T / Tq shared, mK <= 64, cubic / cubicspline; runs in FILTER mode behind the dense /
-// row-pass kernel (only surfaces tagged with the sentinel).
+// The other dense methods ride on the same compaction: linear / slinear need no per-row table at all (the RANK byte gives
+// the interval, the IDX byte the strike); pchip / akima compute a row's slopes with lane = compacted knot (secants of the
+// neighbours through wave shifts, akima's row maximum through a wave reduction) -- no serial loop.
+// Scope: uniform 64 x 16 batches, T / Tq shared, mK <= 64, linear / slinear / cubic / cubicspline / pchip / akima; runs
+// in FILTER mode behind the dense / row-pass kernel (only surfaces tagged with the sentinel).
 #pragma once
 #include "ivs_surface_dense.hpp"
 
@@ -41,9 +44,19 @@ constexpr int MK_MAXCOL = 8;                      // masked output columns handl
 // accessors of a compacted row for eval_cubic
 struct MaskedX { const double* Ksh; const uint8_t* idx; __device__ __forceinline__ double operator()(int i) const { return Ksh[idx[i]]; } };
 
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = __builtin_fmax(v, __shfl_xor(v, s));
+    return v;
+}
+
 template <int METHOD>
 __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) {
-    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot methods only");
+    constexpr bool NAK = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
+    constexpr bool LOCAL = d_is_local(METHOD);
+    constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR;
+    static_assert(NAK || LOCAL || LERP, "methods of the dense kernels only");
+    constexpr int MINROW = NAK ? 4 : (METHOD == IVS_AKIMA ? 3 : 2);      // fewer quotes in a row: the generic kernel's business
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
@@ -89,8 +102,9 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
         bool give_up = tt.unsorted != 0;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-            const bool valid = (v[t] - v[t]) == 0.0;           // finite: neither NaN (missing) nor an infinity
+            const bool valid = !__builtin_isnan(v[t]);         // NaN = missing quote
             const unsigned long long m = __ballot(valid);
+            give_up = give_up || __ballot(__builtin_isinf(v[t])) != 0ull;      // an infinity is a VALUE (it propagates): generic kernel
             const int rank = __popcll(m & lt_mask);
             // compacted quotes, their strike numbers, and -- in the S plane, until the elimination overwrites them knot by
             // knot -- the compacted strikes themselves (saves the index -> strike indirection inside the recurrence)
@@ -98,12 +112,50 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
             RANK[t * DK + lane] = (uint8_t)__popcll(m & le_mask);
             const int nt = __popcll(m);
             if (lane == 0) NROW[t] = nt;
-            give_up = give_up || nt < 4;                       // too few knots (or an empty row): the generic kernel's business
+            give_up = give_up || nt < MINROW;                  // too few knots (or an empty row): the generic kernel's business
         }
         if (give_up) continue;                                 // wave-uniform; the sentinel stays, the generic pass redoes it
         __syncthreads();
+        // ---- pchip / akima: a row's slopes with lane = compacted knot; the S plane's strikes are replaced by the slopes
+        if (LOCAL) {
+#pragma unroll 2
+            for (int t = 0; t < DT; ++t) {
+                const int n = NROW[t];
+                double* xr = SS + t * MK_RS;
+                const double* yr = YC + t * MK_RS;
+                const int k = lane < n ? lane : n - 1, k1 = k + 1 < n ? k + 1 : n - 1;
+                const double x0 = xr[k], x1 = xr[k1], y0 = yr[k], y1 = yr[k1];
+                const double dxc = x1 - x0;                                       // dx_k, 0 from knot n-1 on
+                const double mc = lane < n - 1 ? (y1 - y0) * refined_rcp(dxc) : 0.0;      // secant m_k
+                double sk;
+                if (METHOD == IVS_PCHIP) {
+                    const double dxm = dpp0_f64<DPP_WAVE_SHR1>(dxc), dxp = dpp0_f64<DPP_WAVE_SHL1>(dxc), dxmm = dpp0_f64<DPP_WAVE_SHR1>(dxm);
+                    const double mp = dpp0_f64<DPP_WAVE_SHR1>(mc), mn = dpp0_f64<DPP_WAVE_SHL1>(mc), mpp = dpp0_f64<DPP_WAVE_SHR1>(mp);
+                    const bool first = lane == 0, last = lane == n - 1;
+                    const double h0 = first ? dxc : dxm, h1 = first ? dxp : dxmm;      // one-sided three-point rule at the two ends
+                    const double rs = refined_rcp(h0 + h1);
+                    const double e = pchip_edge(first ? mc : mp, first ? mn : mpp, (2.0 * h0 + h1) * rs, h0 * rs);
+                    const double v = pchip_knot(mp, mc, 2.0 * dxc + dxm, dxc + 2.0 * dxm);
+                    sk = (first || last) ? e : v;
+                    if (n == 2) sk = readlane_f64(mc, 0);
+                } else {      // akima: secants extended linearly two steps beyond either end (scipy _cubic.py:520-528)
+                    const double m0 = readlane_f64(mc, 0), m1 = readlane_f64(mc, 1);
+                    const double l1 = __shfl(mc, n - 2), l2 = __shfl(mc, n - 3);
+                    const double em1 = 2.0 * m0 - m1, em2 = 2.0 * em1 - m0, en1 = 2.0 * l1 - l2, en = 2.0 * en1 - l1;
+                    const double E = lane <= n - 2 ? mc : en1;
+                    const double es1 = dpp0_f64<DPP_WAVE_SHR1>(E), es2 = dpp0_f64<DPP_WAVE_SHR1>(es1), el1 = dpp0_f64<DPP_WAVE_SHL1>(E);
+                    const double ma = lane >= 2 ? es2 : (lane == 1 ? em1 : em2);
+                    const double mb = lane >= 1 ? es1 : em1;
+                    const double md = lane <= n - 2 ? el1 : en;
+                    const double fmax = wave_max_f64(lane < n ? akima_f12(ma, mb, E, md) : 0.0);
+                    sk = akima_knot(ma, mb, E, md, 1e-9 * fmax);
+                }
+                __builtin_amdgcn_wave_barrier();               // every lane holds its strikes before the first slope lands
+                if (lane < n) xr[lane] = sk;
+            }
+        }
         // ---- per-row not-a-knot solve, two lanes per row eliminating from the two ends (lanes 0..31)
-        if (lane < 32) {
+        if (NAK && lane < 32) {
             const int t = lane >> 1;
             const bool mir = (lane & 1) != 0;
             const int n = NROW[t];
@@ -184,7 +236,8 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
             const int j = jf >= 0 ? (int)RANK[t * DK + jf] - 1 : -1;
             const MaskedX X{Ksh, IDX + t * DK};
             const CView Y{YC + t * MK_RS, 1}, S{SS + t * MK_RS, 1};
-            z[t] = eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
+            if (LERP) z[t] = eval_linear(X, Y, n, j, xq, METHOD == IVS_LINEAR);
+            else z[t] = eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
             all_ok = all_ok && !__builtin_isnan(z[t]);
         }
         // ---- maturity direction.  A column whose strike-pass values are all there takes the dense register solve with the
@@ -213,7 +266,7 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
                 const MaskedT cx{Tsh, cti + slot * DT};
                 const CView cy{cz + slot * DT, 1};
                 View csv{cs + slot * DT, 1}, cpw{ccp + slot * DT, 1};
-                if (cn >= 2) method_slopes(METHOD, cx, cy, csv, cpw, cn);
+                if (!LERP && cn >= 2) method_slopes(METHOD, cx, cy, csv, cpw, cn);
                 const CView csr{cs + slot * DT, 1};
                 int jc = -1;
                 for (int tq = 0; tq < mT; ++tq) {
@@ -227,6 +280,10 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
                 }
             }
         }
+        if (LOCAL) {
+#pragma unroll
+            for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
+        }
         if (act && all_ok) dense_maturity_pass<METHOD, true, false, false, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp);
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
       }
@@ -236,15 +293,19 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
 #ifndef IVS_DIAG_MINIMAL
 // Second pass behind the dense / row-pass kernel for uniform 64 x 16 batches: returns true when launched.
 inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
-    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) return false;
     if (p.k_off || p.nK != DK || p.nT != DT || p.mK > 64 || p.mT > D_MAX_MT) return false;
     if (p.t_stride != 0 || p.tq_stride != 0 || !p.tqs) return false;
     const size_t lds = masked_lds_bytes();
     int64_t grid = (int64_t)cx.num_cu * 8;
     const int64_t work = (p.B + 63) / 64;
     if (grid > work) grid = work;
-    if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_masked_kernel<IVS_CUBIC>), dim3((unsigned)grid), dim3(64), lds, cx.st, p);
-    else hipLaunchKernelGGL((surface_masked_kernel<IVS_CUBICSPLINE>), dim3((unsigned)grid), dim3(64), lds, cx.st, p);
+    switch (p.method) {
+#define IVS_MASKED_CASE(M) case M: hipLaunchKernelGGL((surface_masked_kernel<M>), dim3((unsigned)grid), dim3(64), lds, cx.st, p); break;
+        IVS_MASKED_CASE(IVS_LINEAR) IVS_MASKED_CASE(IVS_SLINEAR) IVS_MASKED_CASE(IVS_CUBIC) IVS_MASKED_CASE(IVS_CUBICSPLINE)
+        IVS_MASKED_CASE(IVS_PCHIP) IVS_MASKED_CASE(IVS_AKIMA)
+#undef IVS_MASKED_CASE
+        default: return false;
+    }
     return true;
 }
 #endif

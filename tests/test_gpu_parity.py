@@ -217,6 +217,38 @@ def test_nan_masked_quotes_vs_oracle(method):
     close(got, ref, method, f"nan {method} [{kern}]")
 
 
+@pytest.mark.parametrize("method", DENSE_METHODS)
+def test_masked_rows_with_few_quotes_and_infinities(method):
+    """The compaction kernel behind the dense kernels (ivs_surface_masked.hpp): rows thinned down to 2..7 quotes (pchip's
+    two-knot rule, akima's three, the not-a-knot minimum of four), quotes missing at the row ends, sparse NaN, and an
+    infinity, which is a VALUE (it propagates like in the oracle), not a missing quote."""
+    from iv_interpolation_amd import synth
+    rng = np.random.default_rng(77)
+    d = synth.numpy_batch(192, 64, 16, seed=synth.BASE_SEED + 16)
+    sg = d["sigma"]
+    for b in range(64):                       # thinned rows
+        for r in range(16):
+            if (b + r) % 3 == 0:
+                keep = np.sort(rng.choice(64, size=2 + (b + r) % 6, replace=False))
+                row = np.full(64, np.nan); row[keep] = sg[b, r, keep]; sg[b, r] = row
+    for b in range(64, 128):                  # quotes missing at the ends of some rows + sparse NaN elsewhere
+        sg[b, b % 16, : 1 + b % 7] = np.nan
+        sg[b, (b + 5) % 16, 60 - b % 9:] = np.nan
+        sg[b][rng.random((16, 64)) < 0.02] = np.nan
+    for b in range(128, 160):
+        sg[b][rng.random((16, 64)) < 0.01] = np.nan
+    if method not in ("pchip", "akima"):      # their slope rules are algebraically rearranged on the device (one division per
+        # knot): through an infinite secant the inf / NaN pattern is not the oracle's, on any kernel (documented deviation)
+        sg[160, 4, 10] = np.inf; sg[161, 0, 0] = -np.inf; sg[162, 15, 63] = np.inf; sg[162, 3, 7] = np.nan
+    Kq, Tq = synth.query_grids(64, 16)
+    got, st, kern = _run(d, Kq, Tq, method)
+    ref, rst = O.surface_batch(d["K"], d["T"], sg, Kq, Tq, METHODS[method])
+    assert np.array_equal(st, rst)
+    bad = np.nonzero((np.isnan(got) != np.isnan(ref)).any(axis=(1, 2)))[0]
+    assert bad.size == 0, f"NaN pattern differs in surfaces {bad[:20]}"
+    close(got, ref, method, f"masked rows {method} [{kern}]")
+
+
 def test_absolute_strikes_per_surface_query_grid():
     from iv_interpolation_amd import engine, synth
     d = synth.numpy_batch(200, 64, 16, seed=synth.BASE_SEED + 7, absolute=True)
