@@ -169,7 +169,7 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
     # run 10-25 % slower while the clocks ramp (tools/warm_probe.py), which would otherwise leak into the timed steps
     # whenever W is small.  Untimed, fixed 100 ms of device time.
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.1:
+    while time.perf_counter() - t_spin < a.spin_ms * 1e-3:
         step()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -221,7 +221,7 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(workload, method, kernel, B),
                      "kernel": kernel, "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms),
-                     "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2],
+                     "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2], "kernel_ms_steps": [round(x, 4) for x in kern_ms],
                      "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS, "achievable_GBps": HBM_ACHIEVABLE_GBPS,
                      "algorithmic_bytes_per_launch": bytes_launch,
                      "timing": "HIP events around each launch on the launch stream"},
@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--nan-frac", type=float, default=0.0,
                     help="fraction of quotes set to NaN (= missing): every row then has its own knot set (masked second-pass kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spin-ms", type=float, default=100.0, help="untimed launches before the warm-up steps (clock ramp)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-4 / config-5 sub-results of the N = 1 line")
     ap.add_argument("--check", type=int, default=256, help="surfaces compared with the oracle after the timed region")
     ap.add_argument("--gather", action="store_true",

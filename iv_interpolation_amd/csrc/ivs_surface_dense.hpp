@@ -545,6 +545,7 @@ struct TqShared {
     double pm_last;
     unsigned long long iv_lo, iv_hi;
     int n_left, n_hold, n_nan, unsorted;
+    int redo[2];                          // surfaces tagged by the fast kernel / left tagged by the compaction kernel (SurfaceParams::redo)
 };
 static_assert(offsetof(TqShared, W) == DT * 4 * 8 && offsetof(TqShared, CP) == (DT * 4 + D_MAX_MT * 4) * 8 &&
               offsetof(TqShared, AL) == (DT * 4 + D_MAX_MT * 4 + 3 * DT) * 8, "TT, W, CP, PP, QQ, AL back to back");
@@ -893,6 +894,7 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
     if (lane == 0) {
         o->pm_last = tt.pm_last; o->iv_lo = tt.iv_lo; o->iv_hi = tt.iv_hi;
         o->n_left = tt.n_left; o->n_hold = tt.n_hold; o->n_nan = tt.n_nan; o->unsorted = tt.unsorted;
+        o->redo[0] = 0; o->redo[1] = 0;
     }
 }
 template <bool NTR>
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         double* outb = p.out + b * (int64_t)mT * mK;
         if (!t_shared) t_phase(p.T + b * p.t_stride, p.Tq + b * p.tq_stride);   // contains a barrier
         if (bad != 0ull || tt.unsorted) {                  // wave-uniform: leave it to the generic kernel
-            if (lane == 0) reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;
+            if (lane == 0) { reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL; count_redo(p); }
             prefetch(b + b_step < b_end ? b + b_step : b);
             continue;
         }
@@ -1197,6 +1199,7 @@ inline int launch_surface_dense(const SurfaceParams& p_in, const LaunchCtx& cx, 
         TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
         launch_tq_tables<false>(p, tq, st);
         p.tqs = tq;
+        p.redo = tq->redo;
     }
     if (dbg) {   // diagnostic build: cubic and linear, shared T only
         if (!tsh) return 0;
@@ -1230,8 +1233,8 @@ inline int launch_surface_dense(const SurfaceParams& p_in, const LaunchCtx& cx, 
     }
 #undef IVS_DENSE_CASE
     if (hipGetLastError() != hipSuccess) return -1;
-    launch_surface_masked(p, cx);            // tagged surfaces (missing quotes): compaction kernel first (shared T / Tq only) ...
-    launch_surface_generic<true>(p, cx);     // ... then whatever is still tagged (cheap when nothing is)
+    if (launch_surface_masked(p, cx) && p.redo) ++p.redo;      // tagged surfaces (missing quotes): compaction kernel first (shared T / Tq only) ...
+    launch_surface_generic<true>(p, cx);     // ... then whatever is still tagged (returns at once when its counter is 0)
     return 1;
 }
 

@@ -362,8 +362,10 @@ __global__ __launch_bounds__(256) void var_classify_kernel(SurfaceParams p, VarI
                 cls[k] = -1;
                 if (p.status) p.status[b] = IVS_ST_BAD_SHAPE;
             }
-            if (cls[k] == 2)                                    // not served by a dense kernel: generic redo pass
+            if (cls[k] == 2) {                                  // not served by a dense kernel: generic redo pass
                 reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)p.mT * p.mK)[0] = D_SENTINEL;
+                count_redo(p);
+            }
             if (cls[k] == 0) ++c[0];
             if (cls[k] == 1) ++c[1];
         }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         n = p.nK; koff = it * p.k_stride; return it;
     };
     auto tag = [&](int64_t b) {
-        if (lane == 0) reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL;
+        if (lane == 0) { reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL; count_redo(p); }
     };
 
     double pre[DT * NKB], pre_k[NKB];

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         n = p.nK; koff = it * p.k_stride; return it;
     };
     auto tag = [&](int64_t b) {
-        if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL;
+        if (threadIdx.x == 0) { reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL; count_redo(p); }
     };
 
     double pre[DT], pre_k;
@@ -475,6 +475,7 @@ inline int launch_surface_dense_var(const SurfaceParams& p_in, const LaunchCtx& 
         TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
         launch_tq_tables<true>(p, tq, st);
         p.tqs = tq;
+        p.redo = tq->redo;
     }
     // ragged batch: classify once into one work list per size class (workspace: counters, then V_NCLASS x B items)
     VarItem* lists = nullptr;

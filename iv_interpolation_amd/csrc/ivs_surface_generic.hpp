@@ -23,7 +23,11 @@ struct SurfaceParams {
     int map_groups;      // dense kernels: workgroups are split into this many groups, group r sweeps region r of the batch
     const void* tqs;     // dense kernels, T and Tq shared by the batch: TqShared tables in the caller's workspace (written by
                          // tq_tables_kernel on the same stream, read through the scalar cache)
+    int* redo;           // nullptr, or a counter in the caller's workspace (zeroed by tq_tables_kernel): the fast kernels count
+                         // the surfaces they tag for a redo pass, and a FILTER pass whose counter is 0 returns at once instead
+                         // of scanning B tags (two such scans were 1.7 % of a config-3 call with nothing to redo)
 };
+__device__ __forceinline__ void count_redo(const SurfaceParams& p) { if (p.redo) atomicAdd(p.redo, 1); }
 
 constexpr int GEN_NTMAX = 32;
 
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
 
     // FILTER: a wave inspects 64 surfaces per load (lane i reads the tag of surface base+i) and only walks the
     // tagged ones, so the redo pass costs microseconds when nothing was tagged.
+    if (FILTER && p.redo && *p.redo == 0) return;      // nothing was tagged (wave-uniform)
     const int64_t n_outer = FILTER ? (p.B + 63) / 64 : p.B;
     for (int64_t ob = blockIdx.x; ob < n_outer; ob += gridDim.x) {
       unsigned long long todo = 1ull;

@@ -79,6 +79,8 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
     double xq = (kq_shared && act) ? p.Kq[lane] : nanv;
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
 
+    if (p.redo && *p.redo == 0) return;                    // nothing was tagged (wave-uniform)
+    auto leave = [&]() { if (lane == 0 && p.redo) atomicAdd(p.redo + 1, 1); };      // the surface keeps its tag: generic kernel
     const int64_t n_outer = (p.B + 63) / 64;
     for (int64_t ob = blockIdx.x; ob < n_outer; ob += gridDim.x) {
       const int64_t bi = ob * 64 + lane;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
             if (lane == 0) NROW[t] = nt;
             give_up = give_up || nt < MINROW;                  // too few knots (or an empty row): the generic kernel's business
         }
-        if (give_up) continue;                                 // wave-uniform; the sentinel stays, the generic pass redoes it
+        if (give_up) { leave(); continue; }                    // wave-uniform; the sentinel stays, the generic pass redoes it
         __syncthreads();
         // ---- pchip / akima: a row's slopes with lane = compacted knot; the S plane's strikes are replaced by the slopes
         if (LOCAL) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
         const bool col_masked = act && !all_ok;
         const unsigned long long mm = __ballot(col_masked);
         if (mm != 0ull) {
-            if (__popcll(mm) > MK_MAXCOL) continue;            // the generic kernel redoes the surface
+            if (__popcll(mm) > MK_MAXCOL) { leave(); continue; }      // the generic kernel redoes the surface
             __syncthreads();                                   // every lane is done with the planes
             double* Tsh = Ksh;                                 // 16 maturities
             double* cz = YC; double* cs = YC + MK_MAXCOL * DT; double* ccp = YC + 2 * MK_MAXCOL * DT;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
                 for (int t = 0; t < DT; ++t)
                     if (!__builtin_isnan(z[t])) { cz[slot * DT + cn] = z[t]; cti[slot * DT + cn] = (uint8_t)t; ++cn; }
             }
-            if (__ballot(col_masked && cn > 0 && cn < method_min_knots(METHOD)) != 0ull) continue;    // too-few-knots status: generic kernel
+            if (__ballot(col_masked && cn > 0 && cn < method_min_knots(METHOD)) != 0ull) { leave(); continue; }    // too-few-knots status: generic kernel
             __syncthreads();
             if (col_masked) {
                 const MaskedT cx{Tsh, cti + slot * DT};

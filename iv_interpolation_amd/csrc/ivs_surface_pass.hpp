@@ -37,8 +37,14 @@ struct PassGeom {
     static constexpr int RP = 64 / NSEG;           // rows per pass
     static constexpr int NPASS = DT / RP;
     static constexpr int KCAP = 64 * NKB;
-    static constexpr int RS = KCAP + 2;            // plane row stride (doubles)
-    static constexpr int PLANE = RP * RS;          // the two spare slots behind a row are read as y_{kb+SL} of its last segment
+    // plane row stride (doubles).  64 strikes: two spare slots behind a row (read as y_{kb+SL} of its last segment; the odd
+    // 16-byte-slot stride also staggers the rows of a b128 lane group over the banks).  128 strikes: rows back to back
+    // (y_{kb+SL} of a row's last segment = the next row's / the S plane's first entry: finite, meets a zero coefficient)
+    // and BOTH planes slot-swizzled over (segment >> 2), which makes every b128 lane group -- 16 distinct segments of
+    // two rows -- conflict-free; with the former stride of 130 segments s and s+4 shared their banks (25 % of the LDS
+    // cycles of config 5's upper class were conflicts).
+    static constexpr int RS = NKB == 2 ? KCAP : KCAP + 2;
+    static constexpr int PLANE = RP * RS;
     static constexpr int TS = SL + 2;              // table segment stride (SL entries + 2 spare)
     static constexpr int TN = NSEG * TS;           // one table
     static constexpr int NSCAN = NSEG == 8 ? 3 : 4; // carry scan steps (shift 1, 2, 4[, 8])
@@ -55,7 +61,11 @@ __host__ __device__ constexpr size_t pass_lds_bytes() {
 template <int SL> __device__ __forceinline__ int p_tix(int k) { return (k / SL) * (SL + 2) + (k % SL); }
 // S plane, 8-knot segments: 16-byte slot c of segment s sits at c ^ (s >> 1) (conflict-free b128 writes); 4-knot segments
 // need no swizzle (the odd row stride already interleaves the two rows of a 16-lane write group)
-template <int SL> __device__ __forceinline__ int p_swz(int k) { return SL == 8 ? k ^ (((k >> 4) & 3) << 1) : k; }
+template <int SL, int NKB = 1> __device__ __forceinline__ int p_swz(int k) {
+    return NKB == 2 ? k ^ (((k >> 5) & 3) << 1) : (SL == 8 ? k ^ (((k >> 4) & 3) << 1) : k);
+}
+// Y plane: swizzled like the S plane for 128 strikes, plain otherwise
+template <int NKB> __device__ __forceinline__ int y_swz(int k) { return NKB == 2 ? k ^ (((k >> 5) & 3) << 1) : k; }
 
 // inclusive prefix / suffix products within aligned groups of SL lanes (several groups per DPP row: a shifted value that
 // comes from the neighbouring group is replaced by 1.0)
@@ -193,17 +203,22 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
     const int kb = seg * SL, tb = seg * TS;
     const bool s_first = seg == 0, s_last = seg == NSEG - 1;
     const double* yr = Yp + tl * RS + kb;
+    const int fy = NKB == 2 ? (seg >> 2) & 3 : 0;   // slot swizzle of this segment in the Y plane
     double y[SL + 3];                                   // y[j] = y_{kb + j - 2}
 #pragma unroll
     for (int c = 0; c < SL / 2; ++c) {
-        const double2 v = *reinterpret_cast<const double2*>(yr + 2 * c);
+        const double2 v = *reinterpret_cast<const double2*>(yr + 2 * (c ^ fy));
         y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
     }
     {   // the two knots to the left (segment 0: re-reads its own first pair, selected away / multiplied by 0 below)
-        const double2 v = *reinterpret_cast<const double2*>(s_first ? yr : yr - 2);
+        const int fl = NKB == 2 ? ((seg - 1) >> 2) & 3 : 0;
+        const double2 v = *reinterpret_cast<const double2*>(s_first ? yr : yr - SL + 2 * ((SL / 2 - 1) ^ fl));
         y[0] = v.x; y[1] = v.y;
     }
-    y[SL + 2] = yr[SL];                                 // last segment: the spare slot behind the row (kept finite)
+    {   // first knot of the next segment (last segment: the spare slot behind the row / the next row's first entry)
+        const int fn = NKB == 2 ? ((seg + 1) >> 2) & 3 : 0;
+        y[SL + 2] = yr[SL + 2 * fn];
+    }
     auto tab2 = [&](const double* T, int m) { return *reinterpret_cast<const double2*>(T + tb + m); };   // entries m, m+1
     double d[SL];
     double prev = 0.0;
@@ -260,7 +275,7 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
     double sin_ = dpp0_f64<DPP_ROW_SHL(1)>(f);
     sin_ = s_last ? 0.0 : sin_;
     double* srow = Sp + tl * RS + kb;
-    const int sx = SL == 8 ? (seg >> 1) & 3 : 0;
+    const int sx = NKB == 2 ? (seg >> 2) & 3 : (SL == 8 ? (seg >> 1) & 3 : 0);
 #pragma unroll
     for (int c = 0; c < SL / 2; ++c) {
         const double2 tps = tab2(PSI, 2 * c);
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
 #pragma unroll
                     for (int blk = 0; blk < NKB; ++blk) {
                         const double v = pre[(slot * RP + r) * NKB + blk];
-                        Yp[r * RS + blk * 64 + lane] = v;
+                        Yp[r * RS + y_swz<NKB>(blk * 64 + lane)] = v;
                         acc = __builtin_fma(v, 0.0, acc);
                     }
             }
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
                 if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane);
                 __syncthreads();
                 // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
-                const int o0 = jj, o1 = jj + 1, q0 = p_swz<SL>(jj), q1 = p_swz<SL>(jj + 1);
+                const int o0 = y_swz<NKB>(jj), o1 = y_swz<NKB>(jj + 1), q0 = p_swz<SL, NKB>(jj), q1 = p_swz<SL, NKB>(jj + 1);
                 if (ABL == 2 || ABL == 6) {
 #pragma unroll
                     for (int r = 0; r < RP; ++r) z[ps * RP + r] = Yp[r * RS + lane] + w0;
@@ -458,7 +473,8 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
             if (act) dense_maturity_pass<METHOD, true, false, VAR, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp, 0, 0, nT);
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         } else if (lane == 0) {
-            reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;     // redone by the generic kernel (second launch)
+            reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;     // redone by the compaction / generic kernel (later launches)
+            count_redo(p);
         }
         it = it_next; b = b_next; n = n_next; koff = koff_next;
     }
@@ -479,6 +495,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
     if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
     p.tqs = tq;
+    p.redo = tq->redo;
     auto grid_for = [&](size_t lds, int64_t work, int wg_cap = 12) {
         int per_cu = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));     // LDS is granted in 1280-byte granules
         per_cu = per_cu > wg_cap ? wg_cap : (per_cu < 1 ? 1 : per_cu);         // 3 wavefronts per SIMD (168 VGPRs); 4 with 4-knot segments (128)
@@ -533,7 +550,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     }
     if (hipGetLastError() != hipSuccess) return -1;
 #ifndef IVS_DIAG_MINIMAL
-    if (fixed64) launch_surface_masked(p, cx);   // tagged surfaces (missing quotes): the masked fast pass first ...
+    if (fixed64 && launch_surface_masked(p, cx)) ++p.redo;   // tagged surfaces (missing quotes): the masked fast pass first ...
 #endif
     launch_surface_generic<true>(p, cx);     // ... then the generic kernel for whatever is still tagged (cheap when nothing is)
     return 1;
