@@ -26,6 +26,12 @@
 #define IVS_PASS_SL 8      // knots per segment of the uniform 64 x 16 kernel (8: 12 workgroups / CU, 4: 16)
 #endif
 
+#ifndef IVS_PASS_CAP2
+// workgroups per CU of the 128-strike kernel.  Its 16 896 B of LDS would admit 9, but the surfaces are dealt out statically
+// (stride = grid): with 9 one SIMD of every CU carries three wavefronts, its workgroups run at 2/3 of the others' pace and
+// the launch waits for them (measured 146.9 vs 160.5 M surfaces/s).  Only multiples of 4 are balanced.
+#define IVS_PASS_CAP2 8
+#endif
 #ifndef IVS_PASS_PFP4
 #define IVS_PASS_PFP4 2
 #endif
@@ -54,8 +60,8 @@ struct PassGeom {
 template <int NKB, bool VAR, int SL = 8>
 __host__ __device__ constexpr size_t pass_lds_bytes() {
     using G = PassGeom<NKB, SL>;
-    // Y, S planes; AL CP PP QQ PI PSI [PM] tables; Ksh
-    return (size_t)(2 * G::PLANE + (VAR ? 7 : 6) * G::TN + G::KCAP) * 8;
+    // Y, S planes; AL CP PP QQ PI PSI tables; Ksh
+    return (size_t)(2 * G::PLANE + 6 * G::TN + G::KCAP) * 8;
 }
 
 template <int SL> __device__ __forceinline__ int p_tix(int k) { return (k / SL) * (SL + 2) + (k % SL); }
@@ -95,7 +101,7 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
     constexpr int TS = G::TS;
     constexpr int TN = G::TN, NSEG = G::NSEG;
     double* AL = TB; double* CP = TB + TN; double* PP = TB + 2 * TN; double* QQ = TB + 3 * TN;
-    double* PI = TB + 4 * TN; double* PSI = TB + 5 * TN; double* PM = TB + 6 * TN;
+    double* PI = TB + 4 * TN; double* PSI = TB + 5 * TN;
     double c00 = 1.0, c01 = 0.0, c10 = 0.0, c11 = 1.0;          // product of all matrices of the previous blocks
     double carry_crb = 0.0, carry_rdx = 0.0, carry_rdx_prev = 0.0;
 #pragma unroll
@@ -158,7 +164,7 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
             // row's CP = 0 cuts the backward recurrence off from whatever lies to its right (see factor_tables_var)
             const int kl = p_tix<SL>(ir);
             AL[kl] = in ? al : -1.0; CP[kl] = in ? cp : 0.0; PP[kl] = in ? pp : 0.0; QQ[kl] = in ? qq : 0.0;
-            if (VAR) PM[kl] = in ? pm : 0.0;
+            if (VAR && last) PI[SL + 1] = pm;      // the third tap exists in the last system row only: one scalar, not a table
             PI[kl] = pi; PSI[kl] = psi;
             if ((lane & (SL - 1)) == SL - 1) PI[(ir / SL) * TS + SL] = pi;               // P_j: product of (-AL) over segment j (spare slot)
             if ((lane & (SL - 1)) == 0) PSI[(ir / SL) * TS + SL] = in ? psi : 0.0;       // Q_j: product of (-CP)
@@ -194,14 +200,16 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
 
 // One pass: slopes of the RP rows staged in Yp -> Sp.  All 64 lanes; no barrier inside (the caller brackets it).
 template <int NKB, bool VAR, int SL = 8>
-__device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const double* TB, int lane) {
+__device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const double* TB, int lane, int n) {
     using G = PassGeom<NKB, SL>;
     constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS, TS = G::TS;
     const double* AL = TB; const double* CP = TB + TN; const double* PP = TB + 2 * TN; const double* QQ = TB + 3 * TN;
-    const double* PI = TB + 4 * TN; const double* PSI = TB + 5 * TN; const double* PM = TB + 6 * TN;
+    const double* PI = TB + 4 * TN; const double* PSI = TB + 5 * TN;
+    const double pm_last = VAR ? PI[SL + 1] : 0.0;  // run-time n: third tap of the last system row (wave-uniform)
     const int tl = lane / NSEG, seg = lane % NSEG;
     const int kb = seg * SL, tb = seg * TS;
     const bool s_first = seg == 0, s_last = seg == NSEG - 1;
+    const int mlast = n - 1 - kb;                   // position of the last system row in this lane's segment (VAR)
     const double* yr = Yp + tl * RS + kb;
     const int fy = NKB == 2 ? (seg >> 2) & 3 : 0;   // slot swizzle of this segment in the Y plane
     double y[SL + 3];                                   // y[j] = y_{kb + j - 2}
@@ -225,8 +233,6 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
 #pragma unroll
     for (int mm = 0; mm < SL; mm += 2) {
         const double2 tpp = tab2(PP, mm), tqq = tab2(QQ, mm), tal = tab2(AL, mm);
-        double2 tpm = double2{0.0, 0.0};
-        if (VAR) tpm = tab2(PM, mm);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int m = mm + u;
@@ -234,7 +240,7 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
             if (m == 0) { const double e = y[4] - y[3]; dA = s_first ? dB : dA; dB = s_first ? e : dB; }      // row 0: (dy_0, dy_1)
             if (!VAR && m == SL - 1) { dB = s_last ? dA : dB; dA = s_last ? dM : dA; }                             // row n-1: (dy_{n-3}, dy_{n-2})
             double r = (u ? tpp.y : tpp.x) * dA + (u ? tqq.y : tqq.x) * dB;
-            if (VAR) r += (u ? tpm.y : tpm.x) * dM;
+            if (VAR) r = (m == mlast) ? __builtin_fma(pm_last, dM, r) : r;
             prev = r - (u ? tal.y : tal.x) * prev;
             d[m] = prev;
         }
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
     double* Yp = reinterpret_cast<double*>(smem);
     double* Sp = Yp + G::PLANE;
     double* TB = Sp + G::PLANE;
-    double* Ksh = TB + (VAR ? 7 : 6) * TN;
+    double* Ksh = TB + 6 * TN;
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
     auto nostamp = [](int) {};
 
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
                     w2 = u * omt * omt;
                     w3 = u * t * (t - 1.0);
                 }
-                if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane);
+                if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane, n);
                 __syncthreads();
                 // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
                 const int o0 = y_swz<NKB>(jj), o1 = y_swz<NKB>(jj + 1), q0 = p_swz<SL, NKB>(jj), q1 = p_swz<SL, NKB>(jj + 1);
@@ -541,7 +547,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         }
         if (need2) {
             const size_t lds = pass_lds_bytes<2, true>();
-            const int64_t grid = grid_for(lds, p.B);
+            const int64_t grid = grid_for(lds, p.B, IVS_PASS_CAP2);
             if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 2, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl2);
             else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 2, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl2);
         }

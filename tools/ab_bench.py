@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=1_000_000)
 ap.add_argument("--nk", type=int, default=64); ap.add_argument("--mk", type=int, default=64); ap.add_argument("--mt", type=int, default=16)
 ap.add_argument("--ragged", action="store_true", help="config 5: strike counts lo..hi per surface")
 ap.add_argument("--lo", type=int, default=8); ap.add_argument("--hi", type=int, default=128)
+ap.add_argument("--outs", type=int, default=1, help="time every library on this many separately allocated output buffers (placement sensitivity)")
 ap.add_argument("--check", action="store_true", help="compare the outputs of the libraries (max abs diff vs the first)")
 a = ap.parse_args()
 _p, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
@@ -69,6 +70,25 @@ for r in range(a.rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(i); run(i); run(i); e1.record(); torch.cuda.synchronize()
         times[i].append(e0.elapsed_time(e1) / 3)
+if a.outs > 1:
+    outs = [out] + [torch.empty_like(out) for _ in range(a.outs - 1)]
+    for oi, o in enumerate(outs):
+        out = o
+        row = []
+        for i in range(len(libs)):
+            run(i); tt = []
+            for r in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(i); run(i); run(i); e1.record(); torch.cuda.synchronize()
+                tt.append(e0.elapsed_time(e1) / 3)
+            row.append(sorted(tt)[1])
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        flat = o.view(-1)
+        flat.zero_(); torch.cuda.synchronize()
+        e0.record(); flat.zero_(); flat.zero_(); e1.record(); sm = flat.sum(); sm2 = flat.sum(); e2.record(); torch.cuda.synchronize()
+        gb = flat.numel() * 8 / 1e9
+        print(f"out buffer {oi} at {o.data_ptr():#x} (sigma at {d['sigma'].data_ptr():#x}): " + "  ".join(f"{x:.3f}" for x in row) +
+              f" ms | plain write {2 * gb / (e0.elapsed_time(e1) * 1e-3):.0f} GB/s, plain read {2 * gb / (e1.elapsed_time(e2) * 1e-3):.0f} GB/s")
 for pth, t in zip(a.libs, times):
     t = sorted(t)
     print(f"{pth}: median {t[len(t)//2]:.3f} ms  min {t[0]:.3f} ms  -> {a.batch / t[len(t)//2] / 1e3:.1f} M surfaces/s (median)")
