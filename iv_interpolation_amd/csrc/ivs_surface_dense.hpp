@@ -546,6 +546,8 @@ struct TqShared {
     unsigned long long iv_lo, iv_hi;
     int n_left, n_hold, n_nan, unsorted;
     int redo[2];                          // surfaces tagged by the fast kernel / left tagged by the compaction kernel (SurfaceParams::redo)
+    unsigned long long pad_[7];
+    unsigned long long queue[24 * QUEUE_STRIDE];      // work-queue heads of the row-pass kernels (SurfaceParams::queue)
 };
 static_assert(offsetof(TqShared, W) == DT * 4 * 8 && offsetof(TqShared, CP) == (DT * 4 + D_MAX_MT * 4) * 8 &&
               offsetof(TqShared, AL) == (DT * 4 + D_MAX_MT * 4 + 3 * DT) * 8, "TT, W, CP, PP, QQ, AL back to back");
@@ -896,6 +898,7 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
         o->n_left = tt.n_left; o->n_hold = tt.n_hold; o->n_nan = tt.n_nan; o->unsorted = tt.unsorted;
         o->redo[0] = 0; o->redo[1] = 0;
     }
+    if (lane < 24) o->queue[lane * QUEUE_STRIDE] = 0ull;
 }
 template <bool NTR>
 inline void launch_tq_tables(const SurfaceParams& p, TqShared* o, hipStream_t st) {
@@ -976,15 +979,17 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
     // with its G/R workgroups interleaved.  With R = 1 all 2048 resident workgroups advance through ONE window of the
     // batch; several distant windows at once stream 4-5 % faster (tools/map_probe.hip: 5.60 -> 5.90 TB/s for this
     // kernel's access pattern, the same effect that separates a persistent grid-stride copy from a wide-grid one).
-    const int R = p.map_groups;
-    const int64_t region = (p.B + R - 1) / R;
-    const int64_t base = (int64_t)(blockIdx.x % R) * region;
-    const int64_t b_end = base + region < p.B ? base + region : p.B;          // this group's surfaces: [base, b_end)
-    const int64_t b_step = gridDim.x / R;
-    int64_t b = base + blockIdx.x / R;
-    if (b < b_end) prefetch(b);
+    // Since round 2 the surfaces of a region are CLAIMED from the group's work queue instead of being dealt out with a
+    // fixed stride (WorkQueue, ivs_surface_generic.hpp).
+    WorkQueue wq;
+    wq.init(p.queue, p.map_groups, p.B, WQ_CHUNK, lane);
+    int64_t b = wq.take(), b_next = b >= 0 ? wq.take() : -1;
+    if (b >= 0) prefetch(b);
 
-    for (; b < b_end; b += b_step) {
+    while (b >= 0) {
+        const bool more = b_next >= 0;
+        const WorkQueue::Pending pend = wq.begin(more);
+        auto advance = [&]() { const int64_t n2 = wq.finish(pend, more); b = b_next; b_next = n2; };
         __syncthreads();                                   // everyone is done reading the previous surface's LDS
         stamp(-1);
         // ---- stage quotes: chunk i, lane -> row t = 2i + (lane>>5), k = 2*(lane&31)
@@ -1000,7 +1005,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         if (!t_shared) t_phase(p.T + b * p.t_stride, p.Tq + b * p.tq_stride);   // contains a barrier
         if (bad != 0ull || tt.unsorted) {                  // wave-uniform: leave it to the generic kernel
             if (lane == 0) { reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL; count_redo(p); }
-            prefetch(b + b_step < b_end ? b + b_step : b);
+            prefetch(more ? b_next : b);
+            advance();
             continue;
         }
         __syncthreads();
@@ -1009,8 +1015,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         if (!kq_shared) load_xq(Kqb);
         {   // next surface's loads fly during the whole computation; past the end the last surface is re-read
             // (harmless) so that the prefetch registers are written on every path
-            const int64_t bn = b + b_step;
-            if (ABL != 5) prefetch(bn < b_end ? bn : b);
+            if (ABL != 5) prefetch(more ? b_next : b);
         }
         if (d_is_nak(METHOD) && (ABL == 1 || ABL == 6)) {
             RDX[lane] = 1.0;
@@ -1110,6 +1115,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         }
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         if (STAMP) acc[7] += 1;
+        advance();
     }
     if (STAMP && dbg && lane == 0) {
 #pragma unroll
@@ -1129,7 +1135,7 @@ struct LaunchCtx {
     int map_groups = 0;
 };
 constexpr int IVS_MAX_DEV = 64;
-constexpr size_t WS_TQ_BYTES = 4096;                 // TqShared at offset 0
+constexpr size_t WS_TQ_BYTES = 8192;                 // TqShared at offset 0
 constexpr size_t WS_COUNTS_BYTES = 256;              // ragged: per-class counters
 constexpr int V_NCLASS = 4;                          // ragged: work lists (one per size class), B items each
 static_assert(sizeof(TqShared) <= WS_TQ_BYTES, "TqShared must fit its workspace slot");
@@ -1200,7 +1206,11 @@ inline int launch_surface_dense(const SurfaceParams& p_in, const LaunchCtx& cx, 
         launch_tq_tables<false>(p, tq, st);
         p.tqs = tq;
         p.redo = tq->redo;
+    } else {                                     // per-surface maturities: no table kernel runs, the queue heads are zeroed here
+        if (hipMemsetAsync(reinterpret_cast<TqShared*>(cx.ws)->queue, 0, sizeof(TqShared::queue), st) != hipSuccess) return -1;
     }
+    p.queue = reinterpret_cast<TqShared*>(cx.ws)->queue;
+    if (p.map_groups > 16) p.map_groups = 16;
     if (dbg) {   // diagnostic build: cubic and linear, shared T only
         if (!tsh) return 0;
         if (p.method == IVS_CUBIC) {

@@ -340,7 +340,7 @@ __device__ __forceinline__ void dense_strike_slopes_local_var(const double* Y, d
 // class, so that no kernel walks over -- and reads the offsets of -- the other class's surfaces (that cost 9-18 % of
 // the launch on config 5).  items == nullptr: the launch serves surfaces 0..B-1 of a uniform batch.
 struct VarItem { int32_t b; int32_t n; int64_t koff; };
-struct VarList { const VarItem* items; const int32_t* count; };
+struct VarList { const VarItem* items; const int32_t* count; int qslot = 0; };      // qslot: work-queue head of this launch
 
 __global__ __launch_bounds__(256) void var_classify_kernel(SurfaceParams p, VarItem* l1, VarItem* l2, int32_t* counts) {
     // 1024 consecutive surfaces per block and step, 4 per thread; block-level exclusive scan of the per-thread class
@@ -463,10 +463,14 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         for (int blk = 0; blk < NKB; ++blk) { const int k = blk * 64 + lane; pre_k[blk] = k < nn ? Kb[k] : inf; }
     };
 
-    int64_t it = blockIdx.x, b = 0;
-    if (it < limit) { b = at(it, n, koff); issue_loads(b, koff, n); }
+    WorkQueue wq;                                          // work queues instead of static striding (ivs_surface_generic.hpp)
+    wq.init(p.queue + list.qslot * 8 * QUEUE_STRIDE, 8, limit, WQ_CHUNK, lane);
+    int64_t it = wq.take(), it_next = it >= 0 ? wq.take() : -1, b = 0;
+    if (it >= 0) { b = at(it, n, koff); issue_loads(b, koff, n); }
 
-    while (it < limit) {
+    while (it >= 0) {
+        const bool more = it_next >= 0;
+        const WorkQueue::Pending pend = wq.begin(more);
         __syncthreads();
         unsigned long long bad = 0ull;                     // wave-level NaN mask in scalar registers
 #pragma unroll
@@ -481,9 +485,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
         double* outb = p.out + b * (int64_t)mT * mK;
         const double* Kqb = p.Kq + b * p.kq_stride;
-        const int64_t it_next = it + gridDim.x;
         int64_t b_next = 0;
-        if (it_next < limit) b_next = at(it_next, n_next, koff_next);
+        if (more) b_next = at(it_next, n_next, koff_next);
         if (!TSHARED) dense_t_phase<METHOD, WLDS, true>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, S + 600, TT, W,
                                                         tt, nT, S);
         const bool redo = bad != 0ull || tt.unsorted;
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
             }
             if (!kq_shared) load_xq(Kqb);
         }
-        if (it_next < limit) issue_loads(b_next, koff_next, n_next);   // next surface flies during evaluation + maturity pass
+        if (more) issue_loads(b_next, koff_next, n_next);   // next surface flies during evaluation + maturity pass
         if (!redo) {
 #pragma unroll 1
             for (int q0 = 0, qb = 0; q0 < mK; q0 += 64, ++qb) {
@@ -579,7 +582,8 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
             }
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         }
-        it = it_next; b = b_next; n = n_next; koff = koff_next;
+        const int64_t it_next2 = wq.finish(pend, more);
+        it = it_next; it_next = it_next2; b = b_next; n = n_next; koff = koff_next;
     }
 }
 

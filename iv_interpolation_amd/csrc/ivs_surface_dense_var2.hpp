@@ -476,7 +476,10 @@ inline int launch_surface_dense_var(const SurfaceParams& p_in, const LaunchCtx& 
         launch_tq_tables<true>(p, tq, st);
         p.tqs = tq;
         p.redo = tq->redo;
+    } else {                                     // per-surface maturities: no table kernel runs, the queue heads are zeroed here
+        if (hipMemsetAsync(reinterpret_cast<TqShared*>(cx.ws)->queue, 0, sizeof(TqShared::queue), st) != hipSuccess) return -1;
     }
+    p.queue = reinterpret_cast<TqShared*>(cx.ws)->queue;
     // ragged batch: classify once into one work list per size class (workspace: counters, then V_NCLASS x B items)
     VarItem* lists = nullptr;
     int32_t* counts = nullptr;
@@ -490,7 +493,7 @@ inline int launch_surface_dense_var(const SurfaceParams& p_in, const LaunchCtx& 
         if (cb > cap) cb = cap;
         hipLaunchKernelGGL(var_classify_kernel, dim3((unsigned)cb), dim3(256), 0, st, p, lists, lists + p.B, counts);
     }
-    const VarList wl1{lists, counts}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr};
+    const VarList wl1{lists, counts, 0}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr, 1};
     auto grid_for = [&](size_t lds) {
         int per_cu = (int)((160 * 1024) / lds);
         per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);

@@ -23,10 +23,64 @@ struct SurfaceParams {
     int map_groups;      // dense kernels: workgroups are split into this many groups, group r sweeps region r of the batch
     const void* tqs;     // dense kernels, T and Tq shared by the batch: TqShared tables in the caller's workspace (written by
                          // tq_tables_kernel on the same stream, read through the scalar cache)
+    unsigned long long* queue;   // row-pass kernels: work-queue heads in the caller's workspace (zeroed by tq_tables_kernel), or nullptr
     int* redo;           // nullptr, or a counter in the caller's workspace (zeroed by tq_tables_kernel): the fast kernels count
                          // the surfaces they tag for a redo pass, and a FILTER pass whose counter is 0 returns at once instead
                          // of scanning B tags (two such scans were 1.7 % of a config-3 call with nothing to redo)
 };
+constexpr int QUEUE_STRIDE = 16;     // work-queue heads sit 128 B apart (one per workgroup group / size class)
+
+// Work distribution of the persistent fast kernels.  Static striding (workgroup w takes surfaces w, w + G, ...) left 15 %
+// of the workgroup time idle at the tail of a launch: the workgroups of one launch finished between 2.23 and 3.13 ms
+// (tools/ends_probe.py; the memory system does not serve them evenly).  Surfaces are claimed from work queues instead:
+// one head per workgroup group (group g = blockIdx % R sweeps region g of the batch front to back), a
+// workgroup whose own region is exhausted helps the next group.  One claim = CH consecutive surfaces (a single head
+// claimed surface by surface ran at the atomic unit's pace).  Single-wavefront workgroups only (the ticket is broadcast
+// with readfirstlane).  Use: take() twice for the current and the next item; in the loop, while the current item is
+// processed, `pend = begin()` requests the chunk the item after next may need and `finish(pend)` returns that item at
+// the end of the iteration -- the atomic's latency stays off the critical path.
+struct WorkQueue {
+    unsigned long long* q; int R, g0, goff, gcur, ch, lane; int64_t region, limit, cur_i, cur_end;
+    struct Pending { unsigned long long t; int g; bool need; };
+    __device__ __forceinline__ void init(unsigned long long* heads, int groups, int64_t n_items, int chunk, int lane_) {
+        q = heads; R = groups; limit = n_items; ch = chunk; lane = lane_;
+        g0 = blockIdx.x % R; goff = 0; gcur = g0; region = (limit + R - 1) / R; cur_i = 0; cur_end = 0;
+    }
+    __device__ __forceinline__ unsigned long long claim(int g) const {       // lane 0's return value is the ticket
+        unsigned long long t = 0ull;
+        if (lane == 0) t = atomicAdd(q + g * QUEUE_STRIDE, 1ull);
+        return t;
+    }
+    __device__ __forceinline__ bool resolve(unsigned long long t0, int g) {   // ticket -> chunk; false: group g is exhausted
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)t0), hi = __builtin_amdgcn_readfirstlane((unsigned)(t0 >> 32));
+        const int64_t t = (int64_t)(((unsigned long long)hi << 32) | lo);
+        int64_t gend = (int64_t)(g + 1) * region;
+        gend = gend < limit ? gend : limit;
+        const int64_t s0 = (int64_t)g * region + t * ch;
+        if (t * ch >= region || s0 >= gend) return false;
+        cur_i = s0; cur_end = s0 + ch < gend ? s0 + ch : gend;
+        return true;
+    }
+    __device__ __forceinline__ int64_t take() {                               // next item, claiming synchronously if needed; -1: none left
+        while (cur_i >= cur_end) {
+            if (goff >= R) return -1;
+            if (resolve(claim(gcur), gcur)) break;
+            ++goff; gcur = (g0 + goff) % R;
+        }
+        return cur_i++;
+    }
+    __device__ __forceinline__ Pending begin(bool more) const {
+        Pending pd; pd.g = gcur; pd.need = more && cur_i >= cur_end && goff < R; pd.t = pd.need ? claim(pd.g) : 0ull;
+        return pd;
+    }
+    __device__ __forceinline__ int64_t finish(const Pending& pd, bool more) {
+        if (!more) return -1;
+        if (pd.need && !resolve(pd.t, pd.g)) { ++goff; gcur = (g0 + goff) % R; }
+        return take();
+    }
+};
+constexpr int WQ_CHUNK = 4;
+
 __device__ __forceinline__ void count_redo(const SurfaceParams& p) { if (p.redo) atomicAdd(p.redo, 1); }
 
 constexpr int GEN_NTMAX = 32;

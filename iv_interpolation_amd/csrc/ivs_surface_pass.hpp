@@ -27,10 +27,13 @@
 #endif
 
 #ifndef IVS_PASS_CAP2
-// workgroups per CU of the 128-strike kernel.  Its 16 896 B of LDS would admit 9, but the surfaces are dealt out statically
-// (stride = grid): with 9 one SIMD of every CU carries three wavefronts, its workgroups run at 2/3 of the others' pace and
-// the launch waits for them (measured 146.9 vs 160.5 M surfaces/s).  Only multiples of 4 are balanced.
-#define IVS_PASS_CAP2 8
+// workgroups per CU of the 128-strike kernel (LDS admits 9).  Under STATIC striding 9 lost 8.5 % against 8 (one SIMD of
+// every CU carries three wavefronts, its workgroups ran at 2/3 of the others' pace and the launch waited for them); with
+// the work queues the uneven wavefront counts balance out: 184.9 vs 175.9 M surfaces/s for the 65..128 class.
+#define IVS_PASS_CAP2 12
+#endif
+#ifndef IVS_PASS_CHUNK
+#define IVS_PASS_CHUNK 4      // surfaces per work-queue claim
 #endif
 #ifndef IVS_PASS_PFP4
 #define IVS_PASS_PFP4 2
@@ -294,8 +297,15 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
 // VAR = false: uniform batch of 64 x 16 surfaces (BASELINE configs 2/3), surface -> workgroup mapping as surface_dense_kernel.
 // VAR = true : work list of a size class (n <= 64 * NKB strikes per surface, run-time maturity count), or a uniform
 //              batch with nK != 64.
+#ifdef IVS_PASS_ENDSTAMP      // diagnostic build (tools/pass_api.hip): start / end time of every workgroup, 100 MHz wall clock
+__device__ unsigned long long* d_pass_ends = nullptr;
+#endif
+
 template <int METHOD, int NKB, bool VAR, int SL = 8>
 __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(SurfaceParams p, VarList list) {
+#ifdef IVS_PASS_ENDSTAMP
+    if (threadIdx.x == 0 && d_pass_ends) d_pass_ends[blockIdx.x * 2] = wall_clock64();
+#endif
     using G = PassGeom<NKB, SL>;
     constexpr int RP = G::RP, NPASS = G::NPASS, KCAP = G::KCAP, RS = G::RS, TN = G::TN;
     constexpr int PFP = NKB > 1 ? 1 : (SL == 4 ? IVS_PASS_PFP4 : NPASS);   // passes in flight per lane (8-knot segments, 64 strikes: a whole surface)
@@ -325,20 +335,10 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
     const bool act = lane < mK;
     double xq = (kq_shared && act) ? p.Kq[lane] : nanv;
 
-    // ---- work distribution
-    int64_t it, it_end, it_step;
-    if (!VAR) {
-        const int R = p.map_groups;
-        const int64_t region = (p.B + R - 1) / R;
-        const int64_t base = (int64_t)(blockIdx.x % R) * region;
-        it_end = base + region < p.B ? base + region : p.B;
-        it_step = gridDim.x / R;
-        it = base + blockIdx.x / R;
-    } else {
-        it_end = list.items ? (int64_t)*list.count : p.B;
-        it_step = gridDim.x;
-        it = blockIdx.x;
-    }
+    // ---- work distribution: work queues (WorkQueue, ivs_surface_generic.hpp)
+    WorkQueue wq;
+    if (!VAR) wq.init(p.queue, p.map_groups, p.B, IVS_PASS_CHUNK, lane);
+    else wq.init(p.queue + list.qslot * 8 * QUEUE_STRIDE, 8, list.items ? (int64_t)*list.count : p.B, IVS_PASS_CHUNK, lane);
     auto at = [&](int64_t i, int& n, int64_t& koff) -> int64_t {
         if (VAR && list.items) { const VarItem v = list.items[i]; n = v.n; koff = v.koff; return v.b; }
         n = p.nK; koff = i * p.k_stride; return i;
@@ -376,17 +376,19 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
 
     int n = KCAP, n_next = KCAP;
     int64_t koff = 0, koff_next = 0, b = 0, b_next = 0;
-    if (it < it_end) {
+    int64_t it = wq.take();
+    int64_t it_next = it >= 0 ? wq.take() : -1;
+    if (it >= 0) {
         b = at(it, n, koff);
 #pragma unroll
         for (int ps = 0; ps < PFP; ++ps) issue_pass(b, koff, n, ps);
     }
 
-    while (it < it_end) {
+    while (it >= 0) {
         double* outb = p.out + b * (int64_t)mT * mK;
-        const int64_t it_next = it + it_step;
-        const bool more = it_next < it_end;
+        const bool more = it_next >= 0;
         if (more) b_next = at(it_next, n_next, koff_next);
+        const WorkQueue::Pending pend = wq.begin(more);       // the surface after next may open a new chunk: claim it now
         if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;      // issued ahead of the next prefetch (vmcnt is in order)
         bool ok = !tt.unsorted;
         double z[DT];
@@ -482,8 +484,12 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
             reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;     // redone by the compaction / generic kernel (later launches)
             count_redo(p);
         }
-        it = it_next; b = b_next; n = n_next; koff = koff_next;
+        const int64_t it_next2 = wq.finish(pend, more);
+        it = it_next; it_next = it_next2; b = b_next; n = n_next; koff = koff_next;
     }
+#ifdef IVS_PASS_ENDSTAMP
+    if (threadIdx.x == 0 && d_pass_ends) d_pass_ends[blockIdx.x * 2 + 1] = wall_clock64();
+#endif
 }
 
 // Dispatch of the row-pass kernels.  Returns 1 if dispatched (pass kernel(s) + filtered generic redo pass), 0 if the
@@ -502,6 +508,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
     p.tqs = tq;
     p.redo = tq->redo;
+    p.queue = tq->queue;
     auto grid_for = [&](size_t lds, int64_t work, int wg_cap = 12) {
         int per_cu = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));     // LDS is granted in 1280-byte granules
         per_cu = per_cu > wg_cap ? wg_cap : (per_cu < 1 ? 1 : per_cu);         // 3 wavefronts per SIMD (168 VGPRs); 4 with 4-knot segments (128)
@@ -516,7 +523,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         constexpr int FSL = IVS_PASS_SL;
         const size_t lds = pass_lds_bytes<1, false, FSL>();
         const int64_t grid = grid_for(lds, p.B, FSL == 4 ? 16 : 12);
-        p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);
+        p.map_groups = dense_map_groups(grid, p.B, cx.map_groups > 16 ? 16 : cx.map_groups);      // 16 queue heads
         if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, false, FSL>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
 #ifndef IVS_DIAG_MINIMAL
         else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, false, FSL>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
@@ -537,7 +544,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
             if (cb > cap) cb = cap;
             hipLaunchKernelGGL(var_classify_kernel, dim3((unsigned)cb), dim3(256), 0, st, p, lists, lists + p.B, counts);
         }
-        const VarList wl1{lists, counts}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr};
+        const VarList wl1{lists, counts, 0}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr, 1};
         const bool need1 = p.k_off ? true : p.nK <= 64, need2 = p.nK > 64;
         if (need1) {
             const size_t lds = pass_lds_bytes<1, true>();

@@ -11,14 +11,14 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
                           int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
     ivs::SurfaceParams p;
     p.K = K; p.k_off = k_off; p.k_stride = k_stride; p.nK = nK; p.T = T; p.t_stride = t_stride; p.nT = nT;
-    p.sigma = sigma; p.B = B; p.map_groups = 1; p.tqs = nullptr; p.redo = nullptr; p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;
+    p.sigma = sigma; p.B = B; p.map_groups = 1; p.tqs = nullptr; p.redo = nullptr; p.queue = nullptr; p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;
     p.Tq = Tq; p.tq_stride = tq_stride; p.mT = mT; p.out = out; p.status = status; p.method = method;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t grid = 2048;
     p.map_groups = ivs::dense_map_groups(grid, B, (flags >> 8) & 0xff);
     ivs::TqShared* tq = reinterpret_cast<ivs::TqShared*>(workspace);
     ivs::launch_tq_tables<false>(p, tq, st);
-    p.tqs = tq;
+    p.tqs = tq; p.queue = tq->queue;
     const size_t lds = ivs::dense_lds_bytes(mT);
     if (method == IVS_CUBIC) hipLaunchKernelGGL((ivs::surface_dense_kernel<IVS_CUBIC, true, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);
     else hipLaunchKernelGGL((ivs::surface_dense_kernel<IVS_LINEAR, true, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, nullptr);
