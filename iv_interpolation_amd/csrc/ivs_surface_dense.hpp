@@ -981,6 +981,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
     // kernel's access pattern, the same effect that separates a persistent grid-stride copy from a wide-grid one).
     // Since round 2 the surfaces of a region are CLAIMED from the group's work queue instead of being dealt out with a
     // fixed stride (WorkQueue, ivs_surface_generic.hpp).
+    bool told = false;
     WorkQueue wq;
     wq.init(p.queue, p.map_groups, p.B, WQ_CHUNK, lane);
     int64_t b = wq.take(), b_next = b >= 0 ? wq.take() : -1;
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(64, 2) void surface_dense_kernel(SurfaceParams p, u
         double* outb = p.out + b * (int64_t)mT * mK;
         if (!t_shared) t_phase(p.T + b * p.t_stride, p.Tq + b * p.tq_stride);   // contains a barrier
         if (bad != 0ull || tt.unsorted) {                  // wave-uniform: leave it to the generic kernel
-            if (lane == 0) { reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL; count_redo(p); }
+            if (lane == 0) { reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL; count_redo(p, told); }
             prefetch(more ? b_next : b);
             advance();
             continue;

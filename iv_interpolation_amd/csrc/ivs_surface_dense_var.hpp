@@ -439,8 +439,9 @@ __global__ __launch_bounds__(64, 2) void surface_dense_var_kernel(SurfaceParams 
         if (list.items) { const VarItem v = list.items[it]; n = v.n; koff = v.koff; return v.b; }
         n = p.nK; koff = it * p.k_stride; return it;
     };
+    bool told = false;
     auto tag = [&](int64_t b) {
-        if (lane == 0) { reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL; count_redo(p); }
+        if (lane == 0) { reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL; count_redo(p, told); }
     };
 
     double pre[DT * NKB], pre_k[NKB];

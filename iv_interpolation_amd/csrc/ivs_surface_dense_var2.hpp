@@ -295,8 +295,9 @@ __global__ __launch_bounds__(128, 2) void surface_dense_var2_kernel(SurfaceParam
         if (list.items) { const VarItem v = list.items[it]; n = v.n; koff = v.koff; return v.b; }
         n = p.nK; koff = it * p.k_stride; return it;
     };
+    bool told = false;
     auto tag = [&](int64_t b) {
-        if (threadIdx.x == 0) { reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL; count_redo(p); }
+        if (threadIdx.x == 0) { reinterpret_cast<unsigned long long*>(p.out + b * (int64_t)mT * mK)[0] = D_SENTINEL; count_redo(p, told); }
     };
 
     double pre[DT], pre_k;

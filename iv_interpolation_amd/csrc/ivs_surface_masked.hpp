@@ -80,9 +80,14 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
 
     if (p.redo && *p.redo == 0) return;                    // nothing was tagged (wave-uniform)
-    auto leave = [&]() { if (lane == 0 && p.redo) atomicAdd(p.redo + 1, 1); };      // the surface keeps its tag: generic kernel
+    bool told = false;
+    auto leave = [&]() { if (lane == 0 && p.redo && !told) { *reinterpret_cast<volatile int*>(p.redo + 1) = 1; told = true; } };      // the surface keeps its tag: generic kernel
     const int64_t n_outer = (p.B + 63) / 64;
-    for (int64_t ob = blockIdx.x; ob < n_outer; ob += gridDim.x) {
+    // blocks of 64 tags are claimed from a work queue (head 16 of the workspace; WorkQueue, ivs_surface_generic.hpp): the
+    // tagged surfaces are spread unevenly over the blocks, and so is the speed of the workgroups
+    WorkQueue wq;
+    wq.init(p.queue + 16 * QUEUE_STRIDE, 1, n_outer, 1, lane);
+    for (int64_t ob = p.queue ? wq.take() : (int64_t)blockIdx.x; ob >= 0 && ob < n_outer; ob = p.queue ? wq.take() : ob + gridDim.x) {
       const int64_t bi = ob * 64 + lane;
       const bool tagged = bi < p.B &&
           reinterpret_cast<const unsigned long long*>(p.out + bi * (int64_t)mT * mK)[0] == REDO_SENTINEL;

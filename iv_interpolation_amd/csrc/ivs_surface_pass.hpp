@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
     double xq = (kq_shared && act) ? p.Kq[lane] : nanv;
 
     // ---- work distribution: work queues (WorkQueue, ivs_surface_generic.hpp)
+    bool told = false;
     WorkQueue wq;
     if (!VAR) wq.init(p.queue, p.map_groups, p.B, IVS_PASS_CHUNK, lane);
     else wq.init(p.queue + list.qslot * 8 * QUEUE_STRIDE, 8, list.items ? (int64_t)*list.count : p.B, IVS_PASS_CHUNK, lane);
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         } else if (lane == 0) {
             reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;     // redone by the compaction / generic kernel (later launches)
-            count_redo(p);
+            count_redo(p, told);
         }
         const int64_t it_next2 = wq.finish(pend, more);
         it = it_next; it_next = it_next2; b = b_next; n = n_next; koff = koff_next;
