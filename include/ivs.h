@@ -167,8 +167,10 @@ int ivs_frame_rows(const int64_t* q_off, int64_t n_series, int64_t total_queries
  *   flags  0, or IVS_FLAG_FORCE_GENERIC to bypass the dense fast path (testing / A-B timing); bits 8..15 =
  *          IVS_FLAG_MAP_GROUPS(n): tuning override of the surface -> workgroup mapping of the 64x16 kernel (0 = default)
  *   workspace  ivs_surface_workspace_bytes(B, ragged) bytes of device scratch (ragged = k_off != NULL): the
- *          batch-wide maturity tables (read by the kernels through the scalar cache) and, for ragged batches, the
- *          per-size-class work lists.  Contents are undefined after the call; concurrent calls need distinct workspaces.
+ *          batch-wide maturity tables (read by the kernels through the scalar cache), the work-queue heads and redo
+ *          flags of the persistent kernels (zeroed by the call itself, on the caller's stream) and, for ragged batches,
+ *          the per-size-class work lists.  Contents are undefined after the call; calls that may overlap in time (other
+ *          streams, other threads) need distinct workspaces, calls on one stream may share one.
  */
 enum { IVS_FLAG_FORCE_GENERIC = 1, IVS_FLAG_ONE_PASS = 2 /* testing / A-B timing: skip the row-pass kernels (one-pass dense kernels instead) */ };
 #define IVS_FLAG_MAP_GROUPS(n) (((n) & 0xff) << 8)

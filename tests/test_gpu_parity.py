@@ -629,3 +629,75 @@ def test_buffer_reuse_misaligned_views_and_wide_grids():
     got, _ = engine.surface_batch(dev(clean["K"][:50]), dev(clean["T"]), dev(clean["sigma"][:50]), dev(Kq2), dev(Tq2), "cubic")
     ref, _ = O.surface_batch(clean["K"][:50], clean["T"], clean["sigma"][:50], Kq2, Tq2, O.CUBIC)
     close(got.cpu().numpy(), ref, "cubic", "mK=1000")
+
+
+@pytest.mark.parametrize("method", ["cubic", "linear", "pchip"])
+def test_work_queues_every_surface_exactly_once(method):
+    """The persistent kernels claim their surfaces from work queues (WorkQueue, ivs_surface_generic.hpp).  Batch sizes
+    around the chunk size, the group count and the grid size, uniform and ragged; the output buffer is pre-filled with a
+    marker, so a surface that was never claimed -- or claimed by nobody because a region boundary was mis-computed -- shows."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    Kq, Tq = synth.query_grids(64, 16)
+    marker = -12345.678
+    for B in (1, 2, 3, 5, 7, 8, 9, 31, 33, 63, 64, 65, 257, 3071, 3073, 12289, 24577):
+        d = synth.numpy_batch(B, 64, 16, seed=synth.BASE_SEED + 40 + B)
+        out = torch.full((B, 16, 64), marker, dtype=torch.float64, device="cuda")
+        st = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+        engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method, out=out, status=st)
+        kern = engine.last_kernel()
+        assert "generic" not in kern, kern
+        got = out.cpu().numpy()
+        assert not (got == marker).any(), (B, kern)
+        assert int(st.abs().max()) == 0
+        n = min(B, 300)
+        idx = np.unique(np.linspace(0, B - 1, n).astype(np.int64))
+        ref, _ = O.surface_batch(d["K"][idx], d["T"], d["sigma"][idx], Kq, Tq, METHODS[method])
+        close(got[idx], ref, method, f"queue B={B} {method} [{kern}]")
+    for B in (1, 5, 64, 1000, 9001):
+        d = synth.numpy_ragged_batch(B, 16, 8, 128, seed=synth.BASE_SEED + 41 + B)
+        out = torch.full((B, 16, 64), marker, dtype=torch.float64, device="cuda")
+        engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method, out=out,
+                             k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=16)
+        got = out.cpu().numpy()
+        assert not (got == marker).any(), ("ragged", B)
+        n = min(B, 200)
+        ref, _ = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method], k_off=d["k_off"])
+        close(got[:n], ref[:n], method, f"queue ragged B={B} {method}")
+
+
+def test_surface_call_is_capturable_in_a_graph():
+    """include/ivs.h: no allocation and no synchronisation inside a call.  A hipGraph capture of the call (torch's graph
+    wrapper around hipStreamBeginCapture) fails on either; replays must reproduce the eager result, also after the inputs
+    changed in place (the work-queue heads and redo flags in the workspace are re-zeroed by the captured kernels)."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    B = 20000
+    Kq, Tq = synth.query_grids(64, 16)
+    Kq, Tq = dev(Kq), dev(Tq)
+    for kw_name in ("uniform", "ragged"):
+        if kw_name == "uniform":
+            d = synth.torch_batch(B, 64, 16, seed=synth.BASE_SEED + 50)
+            kw = {}
+        else:
+            d = synth.torch_ragged_batch(B, 16, 8, 128, seed=synth.BASE_SEED + 51)
+            kw = dict(k_off=d["k_off"], nK_max=128, n_maturities=16)
+            engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic", **kw)        # offsets validated (host read-back) outside the capture
+        out = torch.empty((B, 16, 64), dtype=torch.float64, device="cuda")
+        st = torch.empty((B,), dtype=torch.int32, device="cuda")
+        ws = engine.surface_workspace(B, kw_name == "ragged")
+        eager, _ = engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic", **kw)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic", out=out, status=st, workspace=ws, **kw)
+        for rep in range(3):
+            out.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager), (kw_name, rep)
+        d["sigma"].mul_(1.5)                                 # same buffers, new quotes
+        eager2, _ = engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic", **kw)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager2), kw_name
