@@ -53,7 +53,10 @@ struct WorkQueue {
     }
     __device__ __forceinline__ bool resolve(unsigned long long t0, int g) {   // ticket -> chunk; false: group g is exhausted
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)t0), hi = __builtin_amdgcn_readfirstlane((unsigned)(t0 >> 32));
-        const int64_t t = (int64_t)(((unsigned long long)hi << 32) | lo);
+        return resolve_ticket((int64_t)(((unsigned long long)hi << 32) | lo), g);
+    }
+    __device__ __forceinline__ void skip_group() { ++goff; gcur = (g0 + goff) % R; }
+    __device__ __forceinline__ bool resolve_ticket(int64_t t, int g) {        // uniform ticket value -> chunk
         int64_t gend = (int64_t)(g + 1) * region;
         gend = gend < limit ? gend : limit;
         const int64_t s0 = (int64_t)g * region + t * ch;
