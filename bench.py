@@ -165,6 +165,11 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
         engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, method, out=out, status=status,
                              force_generic=a.force_generic, workspace=ws, **kw)
 
+    if dist:
+        # the FIRST collective builds the communicator (hundreds of ms with the device idle): pay it here, before the
+        # clocks are spun up, so that the barrier that brackets the timed region is a warm one
+        dist.barrier()
+        torch.cuda.synchronize()
     # Placement: on this platform the same kernel on the same inputs runs up to 8 % faster or slower depending on WHICH
     # allocation the output lives in (tools/offset_probe.py, tools/ab_bench.py --outs: stable per buffer, independent of
     # offsets inside it, invisible to a plain fill/read of the buffer).  A long-running engine allocates its
@@ -280,6 +285,19 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
     return m
 
 
+class stdout_to_stderr:
+    """File-descriptor level redirect: stdout must carry exactly one JSON line."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,10 +354,13 @@ def main():
     if world > 1 or os.environ.get("IVS_FORCE_DIST") == "1":     # IVS_FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with stdout_to_stderr():       # RCCL prints its version banner on stdout when the communicator is built
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
 
     m = run_workload(torch, engine, synth, sharding, dist, a, a.workload, a.method, a.batch, a.steps, a.warmup, rank, world,
                      backend, scaling, want_sample=(rank == 0 and world == 1 and not a.no_cpu_baseline))
