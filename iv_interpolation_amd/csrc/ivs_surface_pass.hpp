@@ -60,11 +60,11 @@ struct PassGeom {
     static_assert(SL == 8 || (SL == 4 && NKB == 1), "segment length");
     static_assert(NSEG == 8 || NSEG == 16, "a row's segments live in one DPP row");
 };
-template <int NKB, bool VAR, int SL = 8>
+template <int NKB, bool VAR, int SL = 8, bool LERP = false>
 __host__ __device__ constexpr size_t pass_lds_bytes() {
     using G = PassGeom<NKB, SL>;
-    // Y, S planes; AL CP PP QQ PI PSI tables; Ksh
-    return (size_t)(2 * G::PLANE + 6 * G::TN + G::KCAP) * 8;
+    // Y, S planes; AL CP PP QQ PI PSI tables; Ksh  (lerp methods: Y plane and Ksh only)
+    return LERP ? (size_t)(G::PLANE + G::KCAP) * 8 : (size_t)(2 * G::PLANE + 6 * G::TN + G::KCAP) * 8;
 }
 
 template <int SL> __device__ __forceinline__ int p_tix(int k) { return (k / SL) * (SL + 2) + (k % SL); }
@@ -311,14 +311,15 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
     constexpr int PFP = NKB > 1 ? 1 : (SL == 4 ? IVS_PASS_PFP4 : NPASS);   // passes in flight per lane (8-knot segments, 64 strikes: a whole surface)
     constexpr int PPL = RP * NKB;                    // doubles per lane and pass
     static_assert(NPASS % PFP == 0, "prefetch slots rotate with the passes");
-    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot methods only");
+    constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR;      // no slopes: only the Y plane and the strikes live in LDS
+    static_assert(LERP || METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot and lerp methods");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
     double* Yp = reinterpret_cast<double*>(smem);
     double* Sp = Yp + G::PLANE;
     double* TB = Sp + G::PLANE;
-    double* Ksh = TB + 6 * TN;
+    double* Ksh = LERP ? Yp + G::PLANE : TB + 6 * TN;
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
     auto nostamp = [](int) {};
 
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
     const int nT = VAR ? p.nT : DT;
 
     // spare slots that are read but never staged must hold finite numbers (they meet zero coefficients)
-    for (int i = lane; i < 2 * G::PLANE; i += 64) Yp[i] = 0.0;
+    for (int i = lane; i < (LERP ? 1 : 2) * G::PLANE; i += 64) Yp[i] = 0.0;
 
     const bool kq_shared = p.kq_stride == 0;
     const bool act = lane < mK;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
         double z[DT];
         int j = 0, jj = 0;
         double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+        bool l_left = false, l_right = false, l_hold = false, l_slow = false;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int slot = ps % PFP;
@@ -433,8 +435,8 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
             __syncthreads();
             if (ok) {
                 if (ps == 0) {
-                    if (ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB);
-                    // ---- strike search + Hermite weights of this lane's output strike (once per surface)
+                    if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB);
+                    // ---- strike search + weights of this lane's output strike (once per surface)
 #pragma unroll
                     for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
 #pragma unroll
@@ -443,17 +445,44 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
                     const bool left = !(Ksh[0] <= xq);
                     jj = j > n - 2 ? n - 2 : j;
                     const double x0 = Ksh[jj], x1 = Ksh[jj + 1];
-                    const bool okq = !left && ((xq <= xl) || d_extrap_right(METHOD));
-                    const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;
-                    w0 = okq ? (1.0 + 2.0 * t) * omt * omt : nanv;
-                    w1 = t * t * (3.0 - 2.0 * t);
-                    w2 = u * omt * omt;
-                    w3 = u * t * (t - 1.0);
+                    if (LERP) {      // np.interp's interval data; w0..w3 = x0, x1, dx, 1/dx (shared by the 16 rows)
+                        l_left = left; l_right = j >= n - 1;
+                        l_hold = l_right && (METHOD == IVS_LINEAR || xq == xl);
+                        w0 = x0; w1 = x1; w2 = x1 - x0; w3 = refined_rcp(w2);
+                        l_slow = !div_safe(w2);
+                    } else {
+                        const bool okq = !left && ((xq <= xl) || d_extrap_right(METHOD));
+                        const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;
+                        w0 = okq ? (1.0 + 2.0 * t) * omt * omt : nanv;
+                        w1 = t * t * (3.0 - 2.0 * t);
+                        w2 = u * omt * omt;
+                        w3 = u * t * (t - 1.0);
+                    }
+                }
+                const int o0 = y_swz<NKB>(jj), o1 = y_swz<NKB>(jj + 1), q0 = p_swz<SL, NKB>(jj), q1 = p_swz<SL, NKB>(jj + 1);
+                if (LERP) {      // two gathers per row, RP in flight; the same arithmetic (and bits) as the one-pass kernel
+                    double g0[RP], g1[RP];
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) { g0[r] = Yp[r * RS + o0]; g1[r] = Yp[r * RS + o1]; }
+                    bool slow = l_slow;
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) {
+                        double v = lerp_fast(xq, w0, g0[r], g1[r], w2, w3, slow);
+                        if (l_right) v = l_hold ? g1[r] : nanv;      // jj = n - 2 -> g1 is the last quote
+                        if (l_left) v = nanv;
+                        z[ps * RP + r] = v;
+                    }
+                    if (__builtin_expect(__ballot(slow && !l_right && !l_left) != 0ull, 0)) {      // rare: full IEEE path
+                        if (slow && !l_right && !l_left) {
+#pragma unroll
+                            for (int r = 0; r < RP; ++r) z[ps * RP + r] = lerp_np(xq, w0, Yp[r * RS + o0], w1, Yp[r * RS + o1]);
+                        }
+                    }
+                    continue;
                 }
                 if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane, n);
                 __syncthreads();
                 // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
-                const int o0 = y_swz<NKB>(jj), o1 = y_swz<NKB>(jj + 1), q0 = p_swz<SL, NKB>(jj), q1 = p_swz<SL, NKB>(jj + 1);
                 if (ABL == 2 || ABL == 6) {
 #pragma unroll
                     for (int r = 0; r < RP; ++r) z[ps * RP + r] = Yp[r * RS + lane] + w0;
@@ -498,7 +527,8 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
 inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name) {
     SurfaceParams p = p_in;
     hipStream_t st = cx.st;
-    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) return 0;
+    const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR;
+    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || lerp)) return 0;
     if (p.t_stride != 0 || p.tq_stride != 0) return 0;
     if (p.mK > 64 || p.mT > D_MAX_MT) return 0;
     if (p.nT < 4 || p.nT > DT || p.nK < 4 || p.nK > 128) return 0;
@@ -520,16 +550,37 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         return g > work ? work : g;
     };
     const VarList none{nullptr, nullptr};
+    static const char* const names[2][4] = {
+        {"surface_pass_kernel<cubic>", "surface_pass_kernel<cubicspline>", "surface_pass_kernel<linear>", "surface_pass_kernel<slinear>"},
+        {"surface_pass_var_kernel<cubic>", "surface_pass_var_kernel<cubicspline>", "surface_pass_var_kernel<linear>", "surface_pass_var_kernel<slinear>"}};
+    const int mi = p.method == IVS_CUBIC ? 0 : (p.method == IVS_CUBICSPLINE ? 1 : (p.method == IVS_LINEAR ? 2 : 3));
+    // one launch of surface_pass_kernel<method, NKB, VAR, SL> over `list`; the lerp methods carry no S plane and no tables
+#ifdef IVS_DIAG_MINIMAL
+#define IVS_PASS_LAUNCH(NKB_, VAR_, SL_, CAP, LIST)                                                                                      \
+    {                                                                                                                                    \
+        const size_t lds = pass_lds_bytes<NKB_, VAR_, SL_, false>();                                                                     \
+        const int64_t grid = grid_for(lds, p.B, CAP);                                                                                    \
+        if (!(VAR_)) p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);                                                          \
+        hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST);         \
+    }
+#else
+#define IVS_PASS_LAUNCH(NKB_, VAR_, SL_, CAP, LIST)                                                                                      \
+    {                                                                                                                                    \
+        const size_t lds = lerp ? pass_lds_bytes<NKB_, VAR_, SL_, true>() : pass_lds_bytes<NKB_, VAR_, SL_, false>();                    \
+        const int64_t grid = grid_for(lds, p.B, CAP);                                                                                    \
+        if (!(VAR_)) p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);                                                          \
+        switch (p.method) {                                                                                                              \
+            case IVS_CUBIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;             \
+            case IVS_CUBICSPLINE: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
+            case IVS_LINEAR: hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;           \
+            default: hipLaunchKernelGGL((surface_pass_kernel<IVS_SLINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;                  \
+        }                                                                                                                                \
+    }
+#endif
     if (fixed64) {
         constexpr int FSL = IVS_PASS_SL;
-        const size_t lds = pass_lds_bytes<1, false, FSL>();
-        const int64_t grid = grid_for(lds, p.B, FSL == 4 ? 16 : 12);
-        p.map_groups = dense_map_groups(grid, p.B, cx.map_groups > 16 ? 16 : cx.map_groups);      // 16 queue heads
-        if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, false, FSL>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
-#ifndef IVS_DIAG_MINIMAL
-        else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, false, FSL>), dim3((unsigned)grid), dim3(64), lds, st, p, none);
-#endif
-        *name = p.method == IVS_CUBIC ? "surface_pass_kernel<cubic>" : "surface_pass_kernel<cubicspline>";
+        IVS_PASS_LAUNCH(1, false, FSL, (FSL == 4 ? 16 : 12), none)
+        *name = names[0][mi];
     } else {
 #ifdef IVS_DIAG_MINIMAL
         return 0;
@@ -547,21 +598,12 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         }
         const VarList wl1{lists, counts, 0}, wl2{lists ? lists + p.B : nullptr, counts ? counts + 1 : nullptr, 1};
         const bool need1 = p.k_off ? true : p.nK <= 64, need2 = p.nK > 64;
-        if (need1) {
-            const size_t lds = pass_lds_bytes<1, true>();
-            const int64_t grid = grid_for(lds, p.B);
-            if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 1, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);
-            else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 1, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl1);
-        }
-        if (need2) {
-            const size_t lds = pass_lds_bytes<2, true>();
-            const int64_t grid = grid_for(lds, p.B, IVS_PASS_CAP2);
-            if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, 2, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl2);
-            else hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, 2, true>), dim3((unsigned)grid), dim3(64), lds, st, p, wl2);
-        }
-        *name = p.method == IVS_CUBIC ? "surface_pass_var_kernel<cubic>" : "surface_pass_var_kernel<cubicspline>";
+        if (need1) IVS_PASS_LAUNCH(1, true, 8, 12, wl1)
+        if (need2) IVS_PASS_LAUNCH(2, true, 8, IVS_PASS_CAP2, wl2)
+        *name = names[1][mi];
 #endif
     }
+#undef IVS_PASS_LAUNCH
     if (hipGetLastError() != hipSuccess) return -1;
 #ifndef IVS_DIAG_MINIMAL
     if (fixed64 && launch_surface_masked(p, cx)) ++p.redo;   // tagged surfaces (missing quotes): the masked fast pass first ...
