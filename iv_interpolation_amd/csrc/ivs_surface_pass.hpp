@@ -60,11 +60,11 @@ struct PassGeom {
     static_assert(SL == 8 || (SL == 4 && NKB == 1), "segment length");
     static_assert(NSEG == 8 || NSEG == 16, "a row's segments live in one DPP row");
 };
-template <int NKB, bool VAR, int SL = 8, bool LERP = false>
+template <int NKB, bool VAR, int SL = 8, int KIND = 0>      // KIND 0: not-a-knot, 1: lerp, 2: local slopes
 __host__ __device__ constexpr size_t pass_lds_bytes() {
     using G = PassGeom<NKB, SL>;
-    // Y, S planes; AL CP PP QQ PI PSI tables; Ksh  (lerp methods: Y plane and Ksh only)
-    return LERP ? (size_t)(G::PLANE + G::KCAP) * 8 : (size_t)(2 * G::PLANE + 6 * G::TN + G::KCAP) * 8;
+    // Y, S planes; AL CP PP QQ PI PSI tables (local slopes: R0 R1 R2); Ksh  (lerp methods: Y plane and Ksh only)
+    return KIND == 1 ? (size_t)(G::PLANE + G::KCAP) * 8 : (size_t)(2 * G::PLANE + (KIND == 2 ? 3 : 6) * G::TN + G::KCAP) * 8;
 }
 
 template <int SL> __device__ __forceinline__ int p_tix(int k) { return (k / SL) * (SL + 2) + (k % SL); }
@@ -294,6 +294,117 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
     }
 }
 
+// ---- local-slope methods (pchip, akima) on the row-pass structure: no system to solve, three per-knot tables
+// R0 = 1/dx_k (0 from interval n-1 on), R1 / R2 = pchip's weights (the one-sided end coefficients at knots 0 and n-1),
+// rule set of dense_strike_slopes_local[_var] (ivs_surface_dense[_var].hpp) re-cut for 8-knot segments.
+template <int NKB, bool VAR>
+__device__ __forceinline__ void pass_local_tables(const double* X, int n, int lane, double* TB) {
+    using G = PassGeom<NKB, 8>;
+#pragma unroll
+    for (int blk = 0; blk < NKB; ++blk) {
+        const int k = blk * 64 + lane;
+        double r0, r1, r2;
+        local_tables_rt(X, n, k, r0, r1, r2);
+        const int kl = p_tix<8>(k);
+        TB[kl] = r0; TB[G::TN + kl] = r1; TB[2 * G::TN + kl] = r2;
+    }
+    __syncthreads();
+}
+// One pass: local slopes of the RP rows staged in Yp -> Sp.  Lane = (row of the pass, 8-knot segment).  No barrier inside.
+template <int METHOD, int NKB, bool VAR>
+__device__ __forceinline__ void pass_local_slopes(const double* Yp, double* Sp, const double* TB, int lane, int n) {
+    using G = PassGeom<NKB, 8>;
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS, TS = G::TS;
+    const double* R0 = TB; const double* R1 = TB + TN; const double* R2 = TB + 2 * TN;
+    const int tl = lane / NSEG, seg = lane % NSEG;
+    const int kb = seg * 8, tb = seg * TS;
+    const bool s_first = seg == 0;
+    const double* yrow = Yp + tl * RS;
+    const double* yr = yrow + kb;
+    const int fy = NKB == 2 ? (seg >> 2) & 3 : 0;
+    double y[12];                                       // y[i] = y_{kb - 2 + i}
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double2 v = *reinterpret_cast<const double2*>(yr + 2 * (c ^ fy));
+        y[2 + 2 * c] = v.x; y[3 + 2 * c] = v.y;
+    }
+    {   // two knots to the left (segment 0: its own first pair, never used) and two to the right (last segment: the spare
+        // slots behind the row / the next row's first pair: finite, meet secant factors that are replaced or multiplied by 0)
+        const int fl = NKB == 2 ? ((seg - 1) >> 2) & 3 : 0, fn = NKB == 2 ? ((seg + 1) >> 2) & 3 : 0;
+        const double2 l = *reinterpret_cast<const double2*>(s_first ? yr : yr - 8 + 2 * (3 ^ fl));
+        const double2 r = *reinterpret_cast<const double2*>(yr + 8 + 2 * fn);
+        y[0] = l.x; y[1] = l.y; y[10] = r.x; y[11] = r.y;
+    }
+    double F[11];                                       // F[i] = secant of interval kb - 2 + i
+    {
+        const double2 rl = *reinterpret_cast<const double2*>(R0 + (s_first ? tb : tb - TS + 6));       // intervals kb-2, kb-1
+        F[0] = (y[1] - y[0]) * rl.x; F[1] = (y[2] - y[1]) * rl.y;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double2 rr = *reinterpret_cast<const double2*>(R0 + tb + 2 * c);
+            F[2 + 2 * c] = (y[3 + 2 * c] - y[2 + 2 * c]) * rr.x; F[3 + 2 * c] = (y[4 + 2 * c] - y[3 + 2 * c]) * rr.y;
+        }
+        F[10] = (y[11] - y[10]) * R0[tb + TS];                                                          // interval kb+8 (akima only)
+    }
+    double thr = 0.0;
+    if (AK) {   // secants left of knot 0 and from interval n-1 on: linear extension F(i) = 2 F(i-1) - F(i-2)
+        const double l1 = 2.0 * F[2] - F[3], l0 = 2.0 * l1 - F[2];
+        F[1] = s_first ? l1 : F[1]; F[0] = s_first ? l0 : F[0];
+#pragma unroll
+        for (int i = 2; i < 11; ++i) {
+            const int idx = kb - 2 + i;
+            F[i] = (idx == n - 1 || idx == n) ? 2.0 * F[i - 1] - F[i - 2] : F[i];
+        }
+        double fmax = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const double f = akima_f12(F[m], F[m + 1], F[m + 2], F[m + 3]);
+            fmax = (kb + m < n) ? __builtin_fmax(fmax, f) : fmax;
+        }
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));      // the row's 8 (16) segments: aligned lane groups
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
+        fmax = __builtin_fmax(fmax, __shfl_xor(fmax, 4));
+        if (NSEG > 8) fmax = __builtin_fmax(fmax, __shfl_xor(fmax, 8));
+        thr = 1e-9 * fmax;
+    }
+    // pchip: one-sided rule at the last knot n-1, wherever it falls: computed once from LDS, selected in below
+    const int mlast = n - 1 - kb;
+    double e_last = 0.0;
+    if (!AK) {
+        const int k1 = y_swz<NKB>(n - 1), k2 = y_swz<NKB>(n - 2), k3 = y_swz<NKB>(n - 3);
+        const int t1 = p_tix<8>(n - 1), t2 = p_tix<8>(n - 2), t3 = p_tix<8>(n - 3);
+        const double m2 = (yrow[k1] - yrow[k2]) * R0[t2], m3 = (yrow[k2] - yrow[k3]) * R0[t3];
+        e_last = pchip_edge(m2, m3, R1[t1], R2[t1]);
+    }
+    double d[8];
+#pragma unroll
+    for (int mm = 0; mm < 8; mm += 2) {
+        double2 w1 = double2{0.0, 0.0}, w2 = double2{0.0, 0.0};
+        if (!AK) { w1 = *reinterpret_cast<const double2*>(R1 + tb + mm); w2 = *reinterpret_cast<const double2*>(R2 + tb + mm); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = mm + u;
+            double v;
+            if (AK) v = akima_knot(F[m], F[m + 1], F[m + 2], F[m + 3], thr);
+            else {
+                v = pchip_knot(F[m + 1], F[m + 2], u ? w1.y : w1.x, u ? w2.y : w2.x);
+                if (m == 0) { const double e = pchip_edge(F[2], F[3], w1.x, w2.x); v = s_first ? e : v; }
+                v = (m == mlast) ? e_last : v;
+            }
+            d[m] = v;
+        }
+        if (mm == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+    double* srow = Sp + tl * RS + kb;
+    const int sx = NKB == 2 ? (seg >> 2) & 3 : (seg >> 1) & 3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double2 v; v.x = d[2 * c]; v.y = d[2 * c + 1];
+        *reinterpret_cast<double2*>(srow + 2 * (c ^ sx)) = v;
+    }
+}
+
 // VAR = false: uniform batch of 64 x 16 surfaces (BASELINE configs 2/3), surface -> workgroup mapping as surface_dense_kernel.
 // VAR = true : work list of a size class (n <= 64 * NKB strikes per surface, run-time maturity count), or a uniform
 //              batch with nK != 64.
@@ -302,24 +413,30 @@ __device__ unsigned long long* d_pass_ends = nullptr;
 #endif
 
 template <int METHOD, int NKB, bool VAR, int SL = 8>
-__global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(SurfaceParams p, VarList list) {
+// Wavefronts per SIMD: 3 (168 VGPRs); the run-time-shape instantiations of pchip / akima need ~200 (the per-lane maturity
+// solve of the local rules) and run at 2 without scratch -- at 3 they spilled 14-36 registers and lost 3-30 %.
+__global__ __launch_bounds__(64, SL == 4 ? 4 : ((d_is_local(METHOD) && VAR) ? 2 : 3))
+void surface_pass_kernel(SurfaceParams p, VarList list) {
 #ifdef IVS_PASS_ENDSTAMP
     if (threadIdx.x == 0 && d_pass_ends) d_pass_ends[blockIdx.x * 2] = wall_clock64();
 #endif
     using G = PassGeom<NKB, SL>;
     constexpr int RP = G::RP, NPASS = G::NPASS, KCAP = G::KCAP, RS = G::RS, TN = G::TN;
-    constexpr int PFP = NKB > 1 ? 1 : (SL == 4 ? IVS_PASS_PFP4 : NPASS);   // passes in flight per lane (8-knot segments, 64 strikes: a whole surface)
+    // passes in flight per lane (8-knot segments, 64 strikes: a whole surface; the local-slope methods need the registers: one pass)
+    constexpr int PFP = (NKB > 1 || d_is_local(METHOD)) ? 1 : (SL == 4 ? IVS_PASS_PFP4 : NPASS);
     constexpr int PPL = RP * NKB;                    // doubles per lane and pass
     static_assert(NPASS % PFP == 0, "prefetch slots rotate with the passes");
     constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR;      // no slopes: only the Y plane and the strikes live in LDS
-    static_assert(LERP || METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot and lerp methods");
+    constexpr bool LOCAL = d_is_local(METHOD);                                  // pchip / akima: three tables instead of six, no sweeps
+    static_assert(LERP || LOCAL || METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "methods of the dense kernels");
+    static_assert(!LOCAL || SL == 8, "local slopes are cut for 8-knot segments");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
     double* Yp = reinterpret_cast<double*>(smem);
     double* Sp = Yp + G::PLANE;
     double* TB = Sp + G::PLANE;
-    double* Ksh = LERP ? Yp + G::PLANE : TB + 6 * TN;
+    double* Ksh = LERP ? Yp + G::PLANE : TB + (LOCAL ? 3 : 6) * TN;
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
     auto nostamp = [](int) {};
 
@@ -435,7 +552,8 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
             __syncthreads();
             if (ok) {
                 if (ps == 0) {
-                    if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB);
+                    if (LOCAL) pass_local_tables<NKB, VAR>(Ksh, n, lane, TB);
+                    else if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB);
                     // ---- strike search + weights of this lane's output strike (once per surface)
 #pragma unroll
                     for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
@@ -480,7 +598,8 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
                     }
                     continue;
                 }
-                if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane, n);
+                if (LOCAL) pass_local_slopes<METHOD, NKB, VAR>(Yp, Sp, TB, lane, n);
+                else if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane, n);
                 __syncthreads();
                 // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
                 if (ABL == 2 || ABL == 6) {
@@ -508,6 +627,10 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
             }
         }
         if (ok) {
+            if (LOCAL) {
+#pragma unroll
+                for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
+            }
             if (act) dense_maturity_pass<METHOD, true, false, VAR, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp, 0, 0, nT);
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         } else if (lane == 0) {
@@ -522,19 +645,27 @@ __global__ __launch_bounds__(64, SL == 4 ? 4 : 3) void surface_pass_kernel(Surfa
 #endif
 }
 
+// akima exists on the run-time-shape kernels only (the 64 x 16 instantiation would spill at 168 VGPRs and is never built)
+template <int NKB, bool VAR>
+inline void launch_pass_akima(int64_t grid, size_t lds, hipStream_t st, const SurfaceParams& p, const VarList& list) {
+    if constexpr (VAR) hipLaunchKernelGGL((surface_pass_kernel<IVS_AKIMA, NKB, true, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, list);
+}
+
 // Dispatch of the row-pass kernels.  Returns 1 if dispatched (pass kernel(s) + filtered generic redo pass), 0 if the
 // call is outside their scope (see the head of this file), -1 on a launch error.
 inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name) {
     SurfaceParams p = p_in;
     hipStream_t st = cx.st;
     const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR;
-    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || lerp)) return 0;
+    const bool local = d_is_local(p.method);
+    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || lerp || local)) return 0;
     if (p.t_stride != 0 || p.tq_stride != 0) return 0;
     if (p.mK > 64 || p.mT > D_MAX_MT) return 0;
     if (p.nT < 4 || p.nT > DT || p.nK < 4 || p.nK > 128) return 0;
     if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
     if (p.k_off && p.B > 0x7fffffffLL) return 0;
     const bool fixed64 = !p.k_off && p.nK == DK && p.nT == DT && !(reinterpret_cast<uintptr_t>(p.sigma) & 15);
+    if (fixed64 && p.method == IVS_AKIMA) return 0;      // 64 x 16 akima: the one-pass kernel (256 VGPRs) wins -- at 168 it spills 50 registers
     TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
     if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
     p.tqs = tq;
@@ -550,15 +681,18 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         return g > work ? work : g;
     };
     const VarList none{nullptr, nullptr};
-    static const char* const names[2][4] = {
-        {"surface_pass_kernel<cubic>", "surface_pass_kernel<cubicspline>", "surface_pass_kernel<linear>", "surface_pass_kernel<slinear>"},
-        {"surface_pass_var_kernel<cubic>", "surface_pass_var_kernel<cubicspline>", "surface_pass_var_kernel<linear>", "surface_pass_var_kernel<slinear>"}};
-    const int mi = p.method == IVS_CUBIC ? 0 : (p.method == IVS_CUBICSPLINE ? 1 : (p.method == IVS_LINEAR ? 2 : 3));
+    static const char* const names[2][6] = {
+        {"surface_pass_kernel<cubic>", "surface_pass_kernel<cubicspline>", "surface_pass_kernel<linear>", "surface_pass_kernel<slinear>",
+         "surface_pass_kernel<pchip>", "surface_pass_kernel<akima>"},
+        {"surface_pass_var_kernel<cubic>", "surface_pass_var_kernel<cubicspline>", "surface_pass_var_kernel<linear>",
+         "surface_pass_var_kernel<slinear>", "surface_pass_var_kernel<pchip>", "surface_pass_var_kernel<akima>"}};
+    const int mi = p.method == IVS_CUBIC ? 0 : (p.method == IVS_CUBICSPLINE ? 1 : (p.method == IVS_LINEAR ? 2 : (p.method == IVS_SLINEAR ? 3 :
+                   (p.method == IVS_PCHIP ? 4 : 5))));
     // one launch of surface_pass_kernel<method, NKB, VAR, SL> over `list`; the lerp methods carry no S plane and no tables
 #ifdef IVS_DIAG_MINIMAL
 #define IVS_PASS_LAUNCH(NKB_, VAR_, SL_, CAP, LIST)                                                                                      \
     {                                                                                                                                    \
-        const size_t lds = pass_lds_bytes<NKB_, VAR_, SL_, false>();                                                                     \
+        const size_t lds = pass_lds_bytes<NKB_, VAR_, SL_, 0>();                                                                         \
         const int64_t grid = grid_for(lds, p.B, CAP);                                                                                    \
         if (!(VAR_)) p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);                                                          \
         hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST);         \
@@ -566,13 +700,15 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
 #else
 #define IVS_PASS_LAUNCH(NKB_, VAR_, SL_, CAP, LIST)                                                                                      \
     {                                                                                                                                    \
-        const size_t lds = lerp ? pass_lds_bytes<NKB_, VAR_, SL_, true>() : pass_lds_bytes<NKB_, VAR_, SL_, false>();                    \
-        const int64_t grid = grid_for(lds, p.B, CAP);                                                                                    \
+        const size_t lds = lerp ? pass_lds_bytes<NKB_, VAR_, SL_, 1>() : (local ? pass_lds_bytes<NKB_, VAR_, SL_, 2>() : pass_lds_bytes<NKB_, VAR_, SL_, 0>());  \
+        const int64_t grid = grid_for(lds, p.B, (local && (VAR_)) ? 8 : (CAP));            \
         if (!(VAR_)) p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);                                                          \
         switch (p.method) {                                                                                                              \
             case IVS_CUBIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;             \
             case IVS_CUBICSPLINE: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
             case IVS_LINEAR: hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;           \
+            case IVS_PCHIP: hipLaunchKernelGGL((surface_pass_kernel<IVS_PCHIP, NKB_, VAR_, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
+            case IVS_AKIMA: launch_pass_akima<NKB_, VAR_>(grid, lds, st, p, LIST); break;                                                \
             default: hipLaunchKernelGGL((surface_pass_kernel<IVS_SLINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;                  \
         }                                                                                                                                \
     }
