@@ -51,6 +51,8 @@ __host__ __device__ constexpr bool d_is_nak(int m) { return m == IVS_CUBIC || m 
 __host__ __device__ constexpr bool d_is_local(int m) { return m == IVS_PCHIP || m == IVS_AKIMA; }          // 3-/5-point slopes
 __host__ __device__ constexpr bool d_is_hermite(int m) { return d_is_nak(m) || d_is_local(m); }
 __host__ __device__ constexpr bool d_extrap_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }
+// two-knot rules without slopes besides np.interp: nearest / zero / from_derivatives (row-pass kernels only)
+__host__ __device__ constexpr bool d_is_step(int m) { return m == IVS_NEAREST || m == IVS_ZERO || m == IVS_FROM_DERIVATIVES; }
 
 // codes of a query row in the maturity direction
 constexpr int TQ_LEFT = -1, TQ_HOLD = 15, TQ_NAN = 16;
@@ -122,6 +124,18 @@ __device__ __forceinline__ double lerp_fast(double xq, double x0, double y0, dou
     const double aa = __builtin_fabs(a);
     slow |= !((a == 0.0) || (aa >= 0x1p-500 && aa <= 0x1p500)) || __builtin_isnan(res);
     return (x0 == xq) ? y0 : res;
+}
+
+// nearest / zero / from_derivatives on the interval [x0, x1] that holds xq (x0 <= xq < x1, or xq == x1 on the last interval):
+// the arithmetic of eval_nearest / eval_zero / eval_bpoly_linear (ivs_device.hpp) with the interval already known
+template <int METHOD>
+__device__ __forceinline__ double step_eval(double xq, double x0, double x1, double y0, double y1) {
+#pragma clang fp contract(off)
+    if (METHOD == IVS_NEAREST) return (x0 / 2.0 + x1 / 2.0 >= xq) ? y0 : y1;      // ties to the left knot
+    if (METHOD == IVS_ZERO) return (xq == x1) ? y1 : y0;                          // left knot's value; the last knot its own
+    const double s = (xq - x0) / (x1 - x0);
+    const double a = y0 * (1.0 - s), b = y1 * s;
+    return a + b;
 }
 
 // Inclusive scan over lanes 0..N-1 (N = 16 or 64) of 2x2 matrix products P_i <- P_i * P_{i-1} * ... * P_0.
@@ -665,6 +679,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                                                     int nT_rt = DT) {
     const int nT = NTR ? nT_rt : DT;
     constexpr bool CUB = d_is_hermite(METHOD);
+    static_assert(!d_is_step(METHOD) || WLDS, "nearest / zero / from_derivatives: per-row weights only");
     constexpr bool w_lds = WLDS && !SM;
     const double nanv = __builtin_nan("");
     const cdptr cTT = to_const(TT), cW = to_const(W);          // SM only
@@ -855,6 +870,7 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                 if (!mine(tq)) continue;
                 double xt, t0, t1, rdt;                      // {Tq, T_j, T_j+1, 1/(T_j+1 - T_j)}
                 weights(tq, xt, t0, t1, rdt);
+                if (d_is_step(METHOD)) { put(tq, step_eval<METHOD>(xt, t0, t1, z[jv], z[jv + 1])); continue; }
                 const double dt = t1 - t0;
                 bool slow = !div_safe(dt);
                 double r = lerp_fast(xt, t0, z[jv], z[jv + 1], dt, rdt, slow);
@@ -905,7 +921,7 @@ inline void launch_tq_tables(const SurfaceParams& p, TqShared* o, hipStream_t st
 #define IVS_TQ_CASE(M) case M: hipLaunchKernelGGL((tq_tables_kernel<M, NTR>), dim3(1), dim3(64), 0, st, p, o); break;
     switch (p.method) {
         IVS_TQ_CASE(IVS_LINEAR) IVS_TQ_CASE(IVS_CUBIC) IVS_TQ_CASE(IVS_CUBICSPLINE) IVS_TQ_CASE(IVS_SLINEAR)
-        IVS_TQ_CASE(IVS_PCHIP) IVS_TQ_CASE(IVS_AKIMA)
+        IVS_TQ_CASE(IVS_PCHIP) IVS_TQ_CASE(IVS_AKIMA) IVS_TQ_CASE(IVS_NEAREST) IVS_TQ_CASE(IVS_ZERO) IVS_TQ_CASE(IVS_FROM_DERIVATIVES)
         default: break;
     }
 #undef IVS_TQ_CASE

@@ -426,7 +426,8 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
     constexpr int PFP = (NKB > 1 || d_is_local(METHOD)) ? 1 : (SL == 4 ? IVS_PASS_PFP4 : NPASS);
     constexpr int PPL = RP * NKB;                    // doubles per lane and pass
     static_assert(NPASS % PFP == 0, "prefetch slots rotate with the passes");
-    constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR;      // no slopes: only the Y plane and the strikes live in LDS
+    constexpr bool STEP = d_is_step(METHOD);                                   // nearest / zero / from_derivatives
+    constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR || STEP;     // no slopes: only the Y plane and the strikes live in LDS
     constexpr bool LOCAL = d_is_local(METHOD);                                  // pchip / akima: three tables instead of six, no sweeps
     static_assert(LERP || LOCAL || METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "methods of the dense kernels");
     static_assert(!LOCAL || SL == 8, "local slopes are cut for 8-knot segments");
@@ -567,7 +568,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                         l_left = left; l_right = j >= n - 1;
                         l_hold = l_right && (METHOD == IVS_LINEAR || xq == xl);
                         w0 = x0; w1 = x1; w2 = x1 - x0; w3 = refined_rcp(w2);
-                        l_slow = !div_safe(w2);
+                        l_slow = !STEP && !div_safe(w2);
                     } else {
                         const bool okq = !left && ((xq <= xl) || d_extrap_right(METHOD));
                         const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;
@@ -585,11 +586,18 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                     bool slow = l_slow;
 #pragma unroll
                     for (int r = 0; r < RP; ++r) {
-                        double v = lerp_fast(xq, w0, g0[r], g1[r], w2, w3, slow);
-                        if (l_right) v = l_hold ? g1[r] : nanv;      // jj = n - 2 -> g1 is the last quote
+                        double v;
+                        if (STEP) {      // NaN outside the hull; at the last knot the rule itself yields the last quote
+                            v = step_eval<METHOD>(xq, w0, w1, g0[r], g1[r]);
+                            if (l_right && !l_hold) v = nanv;
+                        } else {
+                            v = lerp_fast(xq, w0, g0[r], g1[r], w2, w3, slow);
+                            if (l_right) v = l_hold ? g1[r] : nanv;      // jj = n - 2 -> g1 is the last quote
+                        }
                         if (l_left) v = nanv;
                         z[ps * RP + r] = v;
                     }
+                    if (STEP) continue;
                     if (__builtin_expect(__ballot(slow && !l_right && !l_left) != 0ull, 0)) {      // rare: full IEEE path
                         if (slow && !l_right && !l_left) {
 #pragma unroll
@@ -656,7 +664,7 @@ inline void launch_pass_akima(int64_t grid, size_t lds, hipStream_t st, const Su
 inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, const char** name) {
     SurfaceParams p = p_in;
     hipStream_t st = cx.st;
-    const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR;
+    const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR || d_is_step(p.method);
     const bool local = d_is_local(p.method);
     if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || lerp || local)) return 0;
     if (p.t_stride != 0 || p.tq_stride != 0) return 0;
@@ -681,13 +689,19 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         return g > work ? work : g;
     };
     const VarList none{nullptr, nullptr};
-    static const char* const names[2][6] = {
+    static const char* const names[2][9] = {
         {"surface_pass_kernel<cubic>", "surface_pass_kernel<cubicspline>", "surface_pass_kernel<linear>", "surface_pass_kernel<slinear>",
-         "surface_pass_kernel<pchip>", "surface_pass_kernel<akima>"},
+         "surface_pass_kernel<pchip>", "surface_pass_kernel<akima>", "surface_pass_kernel<nearest>", "surface_pass_kernel<zero>",
+         "surface_pass_kernel<from_derivatives>"},
         {"surface_pass_var_kernel<cubic>", "surface_pass_var_kernel<cubicspline>", "surface_pass_var_kernel<linear>",
-         "surface_pass_var_kernel<slinear>", "surface_pass_var_kernel<pchip>", "surface_pass_var_kernel<akima>"}};
-    const int mi = p.method == IVS_CUBIC ? 0 : (p.method == IVS_CUBICSPLINE ? 1 : (p.method == IVS_LINEAR ? 2 : (p.method == IVS_SLINEAR ? 3 :
-                   (p.method == IVS_PCHIP ? 4 : 5))));
+         "surface_pass_var_kernel<slinear>", "surface_pass_var_kernel<pchip>", "surface_pass_var_kernel<akima>",
+         "surface_pass_var_kernel<nearest>", "surface_pass_var_kernel<zero>", "surface_pass_var_kernel<from_derivatives>"}};
+    int mi = 0;
+    switch (p.method) {
+        case IVS_CUBIC: mi = 0; break; case IVS_CUBICSPLINE: mi = 1; break; case IVS_LINEAR: mi = 2; break; case IVS_SLINEAR: mi = 3; break;
+        case IVS_PCHIP: mi = 4; break; case IVS_AKIMA: mi = 5; break; case IVS_NEAREST: mi = 6; break; case IVS_ZERO: mi = 7; break;
+        default: mi = 8; break;
+    }
     // one launch of surface_pass_kernel<method, NKB, VAR, SL> over `list`; the lerp methods carry no S plane and no tables
 #ifdef IVS_DIAG_MINIMAL
 #define IVS_PASS_LAUNCH(NKB_, VAR_, SL_, CAP, LIST)                                                                                      \
@@ -707,6 +721,9 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
             case IVS_CUBIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;             \
             case IVS_CUBICSPLINE: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
             case IVS_LINEAR: hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;           \
+            case IVS_NEAREST: hipLaunchKernelGGL((surface_pass_kernel<IVS_NEAREST, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;         \
+            case IVS_ZERO: hipLaunchKernelGGL((surface_pass_kernel<IVS_ZERO, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
+            case IVS_FROM_DERIVATIVES: hipLaunchKernelGGL((surface_pass_kernel<IVS_FROM_DERIVATIVES, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
             case IVS_PCHIP: hipLaunchKernelGGL((surface_pass_kernel<IVS_PCHIP, NKB_, VAR_, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
             case IVS_AKIMA: launch_pass_akima<NKB_, VAR_>(grid, lds, st, p, LIST); break;                                                \
             default: hipLaunchKernelGGL((surface_pass_kernel<IVS_SLINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;                  \
