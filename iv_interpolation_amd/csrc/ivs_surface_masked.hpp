@@ -92,17 +92,26 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
       const bool tagged = bi < p.B &&
           reinterpret_cast<const unsigned long long*>(p.out + bi * (int64_t)mT * mK)[0] == REDO_SENTINEL;
       unsigned long long todo = __ballot(tagged);
+      // quotes and strikes of the NEXT tagged surface of the block are requested while the current one is processed
+      double vn[DT], kn = 0.0;
+      auto request = [&](int64_t bb) {
+          const double* sb = p.sigma + bb * (int64_t)(DT * DK);
+#pragma unroll
+          for (int t = 0; t < DT; ++t) vn[t] = sb[t * DK + lane];
+          kn = p.K[bb * p.k_stride + lane];
+      };
+      if (todo) request(ob * 64 + __builtin_ctzll(todo));
       while (todo) {
         const int bit = __builtin_ctzll(todo);
         todo &= todo - 1;
         const int64_t b = ob * 64 + bit;
-        const double* sb = p.sigma + b * (int64_t)(DT * DK);
         double* outb = p.out + b * (int64_t)mT * mK;
         double v[DT];
 #pragma unroll
-        for (int t = 0; t < DT; ++t) v[t] = sb[t * DK + lane];
-        const double kx = p.K[b * p.k_stride + lane];
+        for (int t = 0; t < DT; ++t) v[t] = vn[t];
+        const double kx = kn;
         if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;
+        if (todo) request(ob * 64 + __builtin_ctzll(todo));
         __syncthreads();                                   // the previous surface's readers are done with LDS
         Ksh[lane] = kx;
         // ---- compact every row by ballot; RANK[t][k] = valid knots of row t at or below strike k
