@@ -30,7 +30,8 @@
 namespace ivs {
 
 constexpr int MK_RS = 66;                          // row stride (doubles) of the compacted planes
-__host__ __device__ constexpr size_t masked_lds_bytes() { return (size_t)(2 * DT * MK_RS + DK) * 8 + 2 * DT * DK + DT * 4; }
+// lerp methods keep no per-knot table next to the quotes (their strikes come through the IDX bytes): one plane, 11 KB
+__host__ __device__ constexpr size_t masked_lds_bytes(bool lerp = false) { return (size_t)((lerp ? 1 : 2) * DT * MK_RS + DK) * 8 + 2 * DT * DK + DT * 4; }
 
 // knots of one (possibly mirrored) compacted row: x(j), y(j) for j counted from the lane's own end
 struct MaskedRow {
@@ -51,7 +52,7 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 
 template <int METHOD>
-__global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) {
+__global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR) ? 3 : 2) void surface_masked_kernel(SurfaceParams p) {
     constexpr bool NAK = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
     constexpr bool LOCAL = d_is_local(METHOD);
     constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR;
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
     double* YC = reinterpret_cast<double*>(smem);
-    double* SS = YC + DT * MK_RS;
-    double* Ksh = SS + DT * MK_RS;
+    double* SS = YC + DT * MK_RS;                      // not carved for the lerp methods (never touched)
+    double* Ksh = YC + (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR ? 1 : 2) * DT * MK_RS;
     uint8_t* IDX = reinterpret_cast<uint8_t*>(Ksh + DK);
     uint8_t* RANK = IDX + DT * DK;
     int* NROW = reinterpret_cast<int*>(RANK + DT * DK);
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
             const int rank = __popcll(m & lt_mask);
             // compacted quotes, their strike numbers, and -- in the S plane, until the elimination overwrites them knot by
             // knot -- the compacted strikes themselves (saves the index -> strike indirection inside the recurrence)
-            if (valid) { YC[t * MK_RS + rank] = v[t]; IDX[t * DK + rank] = (uint8_t)lane; SS[t * MK_RS + rank] = kx; }
+            if (valid) { YC[t * MK_RS + rank] = v[t]; IDX[t * DK + rank] = (uint8_t)lane; if (!LERP) SS[t * MK_RS + rank] = kx; }
             RANK[t * DK + lane] = (uint8_t)__popcll(m & le_mask);
             const int nt = __popcll(m);
             if (lane == 0) NROW[t] = nt;
@@ -311,8 +312,9 @@ __global__ __launch_bounds__(64, 2) void surface_masked_kernel(SurfaceParams p) 
 inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
     if (p.k_off || p.nK != DK || p.nT != DT || p.mK > 64 || p.mT > D_MAX_MT) return false;
     if (p.t_stride != 0 || p.tq_stride != 0 || !p.tqs) return false;
-    const size_t lds = masked_lds_bytes();
-    int64_t grid = (int64_t)cx.num_cu * 8;
+    const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR;
+    const size_t lds = masked_lds_bytes(lerp);
+    int64_t grid = (int64_t)cx.num_cu * (lerp ? 12 : 8);
     const int64_t work = (p.B + 63) / 64;
     if (grid > work) grid = work;
     switch (p.method) {
