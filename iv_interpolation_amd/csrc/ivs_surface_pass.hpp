@@ -1,8 +1,8 @@
-// Row-pass kernels: the not-a-knot fast path at 3 wavefronts per SIMD.
+// Row-pass kernels: the fast path of every dense method at 3 wavefronts per SIMD (not-a-knot solve described first).
 //
 // The one-wavefront-per-surface kernels of ivs_surface_dense*.hpp keep the whole surface (two planes of 16 rows) in
 // LDS: 20 KB (64 strikes) or 40 KB (128 strikes), i.e. 8 wavefronts per CU -- and phase ablation (tools/ablate_api.hip,
-// profiles/r02/ablation.txt) shows that at 8 wavefronts the arithmetic is simply ADDED to the streaming time: the
+// profiles/r02/ablation_onepass_*.txt) shows that at 8 wavefronts the arithmetic is simply ADDED to the streaming time: the
 // skeleton (staging + stores) already runs at the device's streaming ceiling.  Here the strike direction is processed
 // in PASSES of RP rows, the planes hold one pass:
 //     64 strikes : 8 rows per pass, 2 passes, lane = (row, segment of 8 knots)     12.8 KB LDS, <= 168 VGPRs: 12 per CU
@@ -16,8 +16,14 @@
 // strikes); S plane the same with the four 16-byte slots of a segment permuted by (segment >> 1) so that the b128 writes
 // of eight neighbouring segments hit eight different bank groups; tables at segment stride 10 (b128 broadcast reads of
 // 8 or 16 segments conflict-free), the scan multipliers in the two spare slots behind each table segment.
-// Scope: cubic / cubicspline, T and Tq shared by the batch, mK <= 64 (one block of output strikes: the pass structure
-// would recompute the slopes per block), 4..16 maturities; everything else stays on the one-pass kernels.
+// 128 strikes: rows back to back (stride 128), both planes slot-swizzled over (segment >> 2).
+// Other methods on the same structure: linear / slinear / nearest / zero / from_derivatives carry no S plane and no tables
+// (a pass = stage, two gathers per row, lerp_fast or step_eval); pchip / akima replace the K-phase and the sweeps by three
+// per-knot tables and per-segment local slopes (pass_local_tables / pass_local_slopes).
+// Work distribution: work queues (WorkQueue, ivs_surface_generic.hpp), not static striding.
+// Scope: T and Tq shared by the batch, mK <= 64 (one block of output strikes: the pass structure would recompute the
+// slopes per block), 4..16 maturities, 4..128 strikes; 64 x 16 akima, per-surface maturities and wider output grids stay on
+// the one-pass kernels; `quadratic` on the generic kernel.
 #pragma once
 #include "ivs_surface_dense_var2.hpp"
 #include "ivs_surface_masked.hpp"
