@@ -124,6 +124,30 @@ def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: O
     return out, status
 
 
+def place_output(run, shape, tries: int = 8, dtype=None, warm: int = 8, timed: int = 3):
+    """Pick the output buffer a persistent caller should keep.  On MI355X the same surface kernel on the same inputs runs up
+    to 8 % faster or slower depending on WHICH allocation it writes to (stable per buffer, independent of offsets inside
+    it).  `run(out)` must launch the call on the current stream with `out` as its output tensor.
+    Allocates `tries` candidates (all alive at once: distinct allocations), times `run` on each with HIP events (median of
+    `timed` after `warm` untimed launches), returns (best_tensor, [median ms per candidate]); the others are freed."""
+    torch = require_device()
+    dtype = dtype or torch.float64
+    cands = [torch.empty(shape, dtype=dtype, device="cuda") for _ in range(max(1, tries))]
+    ms = []
+    for o in cands:
+        for _ in range(warm):
+            run(o)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(timed)]
+        for s_, e_ in evs:
+            s_.record(); run(o); e_.record()
+        torch.cuda.synchronize()
+        ms.append(sorted(s_.elapsed_time(e_) for s_, e_ in evs)[timed // 2])
+    best = cands[ms.index(min(ms))]
+    del cands
+    torch.cuda.empty_cache()
+    return best, ms
+
+
 def last_kernel() -> str:
     return _lib.load().ivs_last_kernel().decode()
 

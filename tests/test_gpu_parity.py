@@ -701,3 +701,22 @@ def test_surface_call_is_capturable_in_a_graph():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, eager2), kw_name
+
+
+def test_place_output_returns_a_usable_buffer():
+    """engine.place_output: candidate allocations timed under the caller's own launch; the returned tensor holds a result."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    B = 4096
+    d = synth.torch_batch(B, 64, 16, seed=synth.BASE_SEED + 60)
+    Kq, Tq = synth.query_grids(64, 16)
+    Kq, Tq = dev(Kq), dev(Tq)
+    st = torch.empty((B,), dtype=torch.int32, device="cuda")
+    ws = engine.surface_workspace(B, False)
+    def run(o):
+        engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic", out=o, status=st, workspace=ws)
+    out, ms = engine.place_output(run, (B, 16, 64), tries=3, warm=2, timed=3)
+    assert len(ms) == 3 and all(m > 0 for m in ms) and tuple(out.shape) == (B, 16, 64)
+    run(out)
+    ref, _ = engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic")
+    assert torch.equal(out, ref)
