@@ -66,10 +66,15 @@ struct PassGeom {
     static_assert(SL == 8 || (SL == 4 && NKB == 1), "segment length");
     static_assert(NSEG == 8 || NSEG == 16, "a row's segments live in one DPP row");
 };
+// 128 strikes, not-a-knot: the in-segment products PI / PSI are not tabulated but rebuilt as running products inside the
+// fix-up loops (the same LDS reads -- AL / CP a second time instead of PI / PSI --, 16 more multiplications per pass), and
+// the strikes alias the S plane (they are dead before the first sweep writes it): 16 896 -> 13 328 B = 9 -> 11 workgroups per CU.
+template <int NKB> __host__ __device__ constexpr bool pass_runp() { return NKB == 2; }
 template <int NKB, bool VAR, int SL = 8, int KIND = 0>      // KIND 0: not-a-knot, 1: lerp, 2: local slopes
 __host__ __device__ constexpr size_t pass_lds_bytes() {
     using G = PassGeom<NKB, SL>;
     // Y, S planes; AL CP PP QQ PI PSI tables (local slopes: R0 R1 R2); Ksh  (lerp methods: Y plane and Ksh only)
+    if (KIND == 0 && pass_runp<NKB>()) return (size_t)(2 * G::PLANE + 4 * G::TN + 2) * 8;
     return KIND == 1 ? (size_t)(G::PLANE + G::KCAP) * 8 : (size_t)(2 * G::PLANE + (KIND == 2 ? 3 : 6) * G::TN + G::KCAP) * 8;
 }
 
@@ -105,10 +110,11 @@ __device__ __forceinline__ double seg_suffix_prod(double v, int lane) {
 // products P_j = prod(-AL) / Q_j = prod(-CP) of every 8-knot segment, and from them the multipliers of the carry scans
 // (see pass_sweeps).  Ends with the tables visible to every lane.
 template <int NKB, bool VAR, int SL = 8>
-__device__ __forceinline__ void pass_factor_tables(const double* X, int n, int lane, double* TB) {
+__device__ __forceinline__ void pass_factor_tables(const double* X, int n, int lane, double* TB, double* SCR = nullptr) {
     using G = PassGeom<NKB, SL>;
     constexpr int TS = G::TS;
     constexpr int TN = G::TN, NSEG = G::NSEG;
+    constexpr bool RUNP = pass_runp<NKB>();         // no PI / PSI tables: segment products go through SCR (free LDS), pm_last behind QQ
     double* AL = TB; double* CP = TB + TN; double* PP = TB + 2 * TN; double* QQ = TB + 3 * TN;
     double* PI = TB + 4 * TN; double* PSI = TB + 5 * TN;
     double c00 = 1.0, c01 = 0.0, c10 = 0.0, c11 = 1.0;          // product of all matrices of the previous blocks
@@ -173,10 +179,16 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
             // row's CP = 0 cuts the backward recurrence off from whatever lies to its right (see factor_tables_var)
             const int kl = p_tix<SL>(ir);
             AL[kl] = in ? al : -1.0; CP[kl] = in ? cp : 0.0; PP[kl] = in ? pp : 0.0; QQ[kl] = in ? qq : 0.0;
-            if (VAR && last) PI[SL + 1] = pm;      // the third tap exists in the last system row only: one scalar, not a table
-            PI[kl] = pi; PSI[kl] = psi;
-            if ((lane & (SL - 1)) == SL - 1) PI[(ir / SL) * TS + SL] = pi;               // P_j: product of (-AL) over segment j (spare slot)
-            if ((lane & (SL - 1)) == 0) PSI[(ir / SL) * TS + SL] = in ? psi : 0.0;       // Q_j: product of (-CP)
+            if (RUNP) {
+                if (VAR && last) TB[4 * TN] = pm;
+                if ((lane & (SL - 1)) == SL - 1) SCR[ir / SL] = pi;
+                if ((lane & (SL - 1)) == 0) SCR[NSEG + ir / SL] = in ? psi : 0.0;
+            } else {
+                if (VAR && last) PI[SL + 1] = pm;      // the third tap exists in the last system row only: one scalar, not a table
+                PI[kl] = pi; PSI[kl] = psi;
+                if ((lane & (SL - 1)) == SL - 1) PI[(ir / SL) * TS + SL] = pi;               // P_j: product of (-AL) over segment j (spare slot)
+                if ((lane & (SL - 1)) == 0) PSI[(ir / SL) * TS + SL] = in ? psi : 0.0;       // Q_j: product of (-CP)
+            }
         }
         if (blk + 1 < NKB) {
             c00 = readlane_f64(p00, 63); c01 = readlane_f64(p01, 63); c10 = readlane_f64(p10, 63); c11 = readlane_f64(p11, 63);
@@ -188,7 +200,7 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
         // P_j P_{j-1} .. P_{j-s+1}; 0 where no such segment exists (it also silences the DPP sources of the neighbouring
         // row when two rows share a DPP row).  Backward: Q_j .. Q_{j+s-1} and the segment to the right.
         const int j = lane < NSEG ? lane : NSEG - 1;
-        double pw = lane < NSEG ? PI[j * TS + SL] : 1.0, qw = lane < NSEG ? PSI[j * TS + SL] : 1.0;
+        double pw = lane < NSEG ? (RUNP ? SCR[j] : PI[j * TS + SL]) : 1.0, qw = lane < NSEG ? (RUNP ? SCR[NSEG + j] : PSI[j * TS + SL]) : 1.0;
         double fm[4], bm[4];
 #pragma unroll
         for (int s = 0; s < G::NSCAN; ++s) {
@@ -213,8 +225,9 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
     using G = PassGeom<NKB, SL>;
     constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS, TS = G::TS;
     const double* AL = TB; const double* CP = TB + TN; const double* PP = TB + 2 * TN; const double* QQ = TB + 3 * TN;
+    constexpr bool RUNP = pass_runp<NKB>();
     const double* PI = TB + 4 * TN; const double* PSI = TB + 5 * TN;
-    const double pm_last = VAR ? PI[SL + 1] : 0.0;  // run-time n: third tap of the last system row (wave-uniform)
+    const double pm_last = VAR ? (RUNP ? TB[4 * TN] : PI[SL + 1]) : 0.0;  // run-time n: third tap of the last system row (wave-uniform)
     const int tl = lane / NSEG, seg = lane % NSEG;
     const int kb = seg * SL, tb = seg * TS;
     const bool s_first = seg == 0, s_last = seg == NSEG - 1;
@@ -267,13 +280,24 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
     din = s_first ? 0.0 : din;
     // ---- local backward sweep with the forward fix-up folded in
     double nxt = 0.0;
+    if (RUNP) {      // PI rebuilt as a running product of (-AL), front to back, before the backward sweep
+        double pi = 1.0;
+#pragma unroll
+        for (int mm = 0; mm < SL; mm += 2) {
+            const double2 tal = tab2(AL, mm);
+            pi *= -tal.x; d[mm] = __builtin_fma(pi, din, d[mm]);
+            pi *= -tal.y; d[mm + 1] = __builtin_fma(pi, din, d[mm + 1]);
+        }
+    }
 #pragma unroll
     for (int mm = SL - 2; mm >= 0; mm -= 2) {
-        const double2 tpi = tab2(PI, mm), tcp = tab2(CP, mm);
+        double2 tpi = double2{0.0, 0.0};
+        if (!RUNP) tpi = tab2(PI, mm);
+        const double2 tcp = tab2(CP, mm);
 #pragma unroll
         for (int u = 1; u >= 0; --u) {
             const int m = mm + u;
-            const double dp = d[m] + (u ? tpi.y : tpi.x) * din;
+            const double dp = RUNP ? d[m] : d[m] + (u ? tpi.y : tpi.x) * din;
             nxt = dp - (u ? tcp.y : tcp.x) * nxt;
             d[m] = nxt;
         }
@@ -291,6 +315,18 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
     sin_ = s_last ? 0.0 : sin_;
     double* srow = Sp + tl * RS + kb;
     const int sx = NKB == 2 ? (seg >> 2) & 3 : (SL == 8 ? (seg >> 1) & 3 : 0);
+    if (RUNP) {      // PSI rebuilt as a running product of (-CP), back to front
+        double psi = 1.0;
+#pragma unroll
+        for (int c = SL / 2 - 1; c >= 0; --c) {
+            const double2 tcp = tab2(CP, 2 * c);
+            double2 v;
+            psi *= -tcp.y; v.y = __builtin_fma(psi, sin_, d[2 * c + 1]);
+            psi *= -tcp.x; v.x = __builtin_fma(psi, sin_, d[2 * c]);
+            *reinterpret_cast<double2*>(srow + 2 * (c ^ sx)) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < SL / 2; ++c) {
         const double2 tps = tab2(PSI, 2 * c);
@@ -443,7 +479,9 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
     double* Yp = reinterpret_cast<double*>(smem);
     double* Sp = Yp + G::PLANE;
     double* TB = Sp + G::PLANE;
-    double* Ksh = LERP ? Yp + G::PLANE : TB + (LOCAL ? 3 : 6) * TN;
+    constexpr bool RUNP = !LERP && !LOCAL && pass_runp<NKB>();
+    // strikes: behind the tables; 128-strike not-a-knot kernels park them in the S plane (dead before the first sweep writes it)
+    double* Ksh = LERP ? Yp + G::PLANE : (RUNP ? Sp : TB + (LOCAL ? 3 : 6) * TN);
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
     auto nostamp = [](int) {};
 
@@ -560,7 +598,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
             if (ok) {
                 if (ps == 0) {
                     if (LOCAL) pass_local_tables<NKB, VAR>(Ksh, n, lane, TB);
-                    else if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB);
+                    else if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB, Sp + KCAP);
                     // ---- strike search + weights of this lane's output strike (once per surface)
 #pragma unroll
                     for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
