@@ -548,6 +548,17 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
         for (int ps = 0; ps < PFP; ++ps) issue_pass(b, koff, n, ps);
     }
 
+    // Strike-dependent state survives from surface to surface: consecutive snapshots of one option chain (and every batch with
+    // a shared strike grid) repeat their strikes, and then the K-phase -- a quarter of the kernel's arithmetic -- is skipped.
+    int j = 0, jj = 0;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+    bool l_left = false, l_right = false, l_hold = false, l_slow = false;
+    double kprev[NKB];
+#pragma unroll
+    for (int blk = 0; blk < NKB; ++blk) kprev[blk] = nanv;
+    int n_prev = -1;
+    bool tables_ok = false;
+
     while (it >= 0) {
         double* outb = p.out + b * (int64_t)mT * mK;
         const bool more = it_next >= 0;
@@ -556,9 +567,8 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
         if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;      // issued ahead of the next prefetch (vmcnt is in order)
         bool ok = !tt.unsorted;
         double z[DT];
-        int j = 0, jj = 0;
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
-        bool l_left = false, l_right = false, l_hold = false, l_slow = false;
+        bool same_k = false;                               // this surface's strikes are the previous surface's: tables (and, with a
+                                                           // shared query grid, the interval search and weights) are kept
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int slot = ps % PFP;
@@ -585,10 +595,18 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                     }
             }
             if (ps == 0) {
+                bool same = tables_ok && n == n_prev;
 #pragma unroll
-                for (int blk = 0; blk < NKB; ++blk) Ksh[blk * 64 + lane] = pre_k[blk];
+                for (int blk = 0; blk < NKB; ++blk) {
+                    Ksh[blk * 64 + lane] = pre_k[blk];
+                    same = same && __ballot(pre_k[blk] != kprev[blk]) == 0ull;      // NaN strikes never compare equal
+                    kprev[blk] = pre_k[blk];
+                }
+                n_prev = n;
+                same_k = same;
             }
             ok = ok && __ballot(acc != 0.0) == 0ull;
+            if (ps == 0) tables_ok = ok;                       // a surface that is redone elsewhere leaves no tables behind
             {                                                  // the slot's registers are free: request the pass PFP ahead
                 const int nx = ps + PFP;
                 if (nx < NPASS) issue_pass(b, koff, n, nx);
@@ -596,10 +614,13 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
             }
             __syncthreads();
             if (ok) {
-                if (ps == 0) {
+                if (ps == 0 && !same_k) {
                     if (LOCAL) pass_local_tables<NKB, VAR>(Ksh, n, lane, TB);
                     else if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB, Sp + KCAP);
-                    // ---- strike search + weights of this lane's output strike (once per surface)
+                }
+                if (ps == 0 && !(same_k && kq_shared)) {
+                    // ---- strike search + weights of this lane's output strike (once per strike grid / query grid)
+                    j = 0;
 #pragma unroll
                     for (int m = 1; m < 8 * NKB; ++m) j += (Ksh[8 * m] <= xq) ? 8 : 0;
 #pragma unroll

@@ -720,3 +720,47 @@ def test_place_output_returns_a_usable_buffer():
     run(out)
     ref, _ = engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic")
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("method", ["cubic", "pchip", "linear", "akima"])
+def test_repeated_strike_grids_reuse_the_tables(method):
+    """Row-pass kernels keep the strike-dependent tables (and, with a shared query grid, the interval search) when a surface
+    repeats the strikes of the one before it -- snapshots of one option chain, or a batch-wide strike grid.  Runs of equal
+    strike rows, interrupted by surfaces with missing quotes (redone elsewhere: they must not leave stale tables behind),
+    shared and per-surface query strikes, uniform and ragged."""
+    from iv_interpolation_amd import engine, synth
+    rng = np.random.default_rng(5)
+    B = 3000
+    d = synth.numpy_batch(B, 64, 16, seed=synth.BASE_SEED + 70)
+    d["K"] = d["K"][(np.arange(B) // 7) * 7]                   # runs of 7 equal strike rows
+    d["sigma"][::53, 3, 10] = np.nan                           # a tagged surface in the middle of some runs
+    Kq, Tq = synth.query_grids(64, 16)
+    got, st, kern = _run(d, Kq, Tq, method)
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
+    assert np.array_equal(st, rst)
+    close(got, ref, method, f"runs of equal strikes {method} [{kern}]")
+    # one strike grid for the whole batch (k_stride = 0) and per-surface query strikes
+    K1 = d["K"][0].copy()
+    Kqb = np.sort(K1[None, :] * (1.0 + 0.01 * rng.standard_normal((B, 64))), axis=1)
+    out, st2 = engine.surface_batch(dev(K1), dev(d["T"]), dev(d["sigma"]), dev(Kqb), dev(Tq), method)
+    ref2, rst2 = O.surface_batch(np.ascontiguousarray(np.broadcast_to(K1, (B, 64))), d["T"], d["sigma"], Kqb, Tq, METHODS[method])
+    assert np.array_equal(st2.cpu().numpy(), rst2)
+    close(out.cpu().numpy(), ref2, method, f"shared strike grid, per-surface queries {method}")
+    # ragged: strike counts in runs of 4 (work-list neighbours of one size class), strikes repeated inside a run
+    Br = 600
+    rr = np.random.default_rng(9)
+    nk = np.repeat(rr.integers(8, 129, Br // 4), 4)
+    off = np.concatenate([[0], np.cumsum(nk)]).astype(np.int64)
+    Kr = np.empty(int(off[-1])); sg = np.empty(16 * int(off[-1]))
+    for b in range(Br):
+        one = synth.numpy_batch(1, int(nk[b]), 16, seed=1000 + (b // 4 if b % 4 else 7 * b))      # b % 4 != 0: the run's strikes
+        if b % 4:
+            Kr[off[b]:off[b + 1]] = Kr[off[b - 1]:off[b]]
+        else:
+            Kr[off[b]:off[b + 1]] = one["K"][0]
+        sg[16 * off[b]:16 * off[b + 1]] = synth.numpy_batch(1, int(nk[b]), 16, seed=5000 + b)["sigma"][0].ravel()
+    out, st3 = engine.surface_batch(dev(Kr), dev(d["T"]), dev(sg), dev(Kq), dev(Tq), method,
+                                    k_off=dev(off), nK_max=int(nk.max()), n_maturities=16)
+    ref3, rst3 = O.surface_batch(Kr, d["T"], sg, Kq, Tq, METHODS[method], k_off=off)
+    assert np.array_equal(st3.cpu().numpy(), rst3)
+    close(out.cpu().numpy(), ref3, method, f"ragged with repeated strikes {method}")

@@ -13,8 +13,9 @@ cases = {"shared T, Tq, Kq (benchmark layout)": (d["K"], d["T"], Kq, Tq),
          "per-surface T and Tq": (d["K"], Tb, Kq, Tqb),
          "per-surface Kq": (d["K"], d["T"], Kqb, Tq),
          "per-surface T, Tq and Kq": (d["K"], Tb, Kqb, Tqb),
-         "shared strikes (one K row)": (d["K"][0].contiguous(), d["T"], Kq, Tq)}
-for method in ("cubic", "linear"):
+         "shared strikes (one K row)": (d["K"][0].contiguous(), d["T"], Kq, Tq),
+         "strike rows in runs of 8 (snapshots of one chain)": (d["K"][(torch.arange(B, device="cuda") // 8) * 8].contiguous(), d["T"], Kq, Tq)}
+for method in ("cubic", "pchip", "linear"):
     for name, (K, T, kq, tq) in cases.items():
         run = lambda: engine.surface_batch(K, T, d["sigma"], kq, tq, method, out=out, status=st)
         for _ in range(3): run()
