@@ -70,6 +70,7 @@ struct PassGeom {
 // fix-up loops (the same LDS reads -- AL / CP a second time instead of PI / PSI --, 16 more multiplications per pass), and
 // the strikes alias the S plane (they are dead before the first sweep writes it): 16 896 -> 13 328 B = 9 -> 11 workgroups per CU.
 template <int NKB> __host__ __device__ constexpr bool pass_runp() { return NKB == 2; }
+constexpr int PASS_TQ_DOUBLES = DT * 4 + D_WLDS_MAX_MT * 4;      // per-surface maturity tables TT + W (TSH = false)
 template <int NKB, bool VAR, int SL = 8, int KIND = 0>      // KIND 0: not-a-knot, 1: lerp, 2: local slopes
 __host__ __device__ constexpr size_t pass_lds_bytes() {
     using G = PassGeom<NKB, SL>;
@@ -454,7 +455,7 @@ __device__ __forceinline__ void pass_local_slopes(const double* Yp, double* Sp, 
 __device__ unsigned long long* d_pass_ends = nullptr;
 #endif
 
-template <int METHOD, int NKB, bool VAR, int SL = 8>
+template <int METHOD, int NKB, bool VAR, int SL = 8, bool TSH = true>
 // Wavefronts per SIMD: 3 (168 VGPRs); the run-time-shape instantiations of pchip / akima need ~200 (the per-lane maturity
 // solve of the local rules) and run at 2 without scratch -- at 3 they spilled 14-36 registers and lost 3-30 %.
 __global__ __launch_bounds__(64, SL == 4 ? 4 : ((d_is_local(METHOD) && VAR) ? 2 : 3))
@@ -485,10 +486,18 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
     const double nanv = __builtin_nan(""), inf = __builtin_inf();
     auto nostamp = [](int) {};
 
+    // TSH = false: maturities / query maturities differ per surface (time to expiry shrinks from snapshot to snapshot): the
+    // T-phase runs per surface into LDS tables of its own (TT, W: 1 KB behind everything else), scratch = the planes, which
+    // are free between two surfaces; mT <= 16 (weights in LDS).  Shipped for `linear` only: the not-a-knot instantiations hold
+    // the solve tables in VGPRs (no scalar cache without batch-wide tables), spilled 70-80 registers and ran at 153 instead of
+    // the one-pass kernel's 242 M surfaces/s.
+    static_assert(TSH || METHOD == IVS_LINEAR, "per-surface maturities: linear only (the not-a-knot instantiations spilled 70-80 registers)");
+    double* TTl = (LERP ? Ksh + KCAP : (RUNP ? TB + 4 * TN + 2 : Ksh + KCAP));
+    double* Wl = TTl + DT * 4;
     TqTables tt;
     const double* TTp = nullptr;
     const double* Wp = nullptr;
-    tq_from_shared(p.tqs, tt, TTp, Wp);
+    if (TSH) tq_from_shared(p.tqs, tt, TTp, Wp);
     const int nT = VAR ? p.nT : DT;
 
     // spare slots that are read but never staged must hold finite numbers (they meet zero coefficients)
@@ -565,6 +574,12 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
         if (more) b_next = at(it_next, n_next, koff_next);
         const WorkQueue::Pending pend = wq.begin(more);       // the surface after next may open a new chunk: claim it now
         if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;      // issued ahead of the next prefetch (vmcnt is in order)
+        if (!TSH) {
+            __syncthreads();                                   // the previous surface is done with the planes and with TT / W
+            dense_t_phase<METHOD, true, VAR>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, LERP ? Yp : Yp + 600, TTl, Wl, tt, nT, Yp);
+            // the scratch may leave non-finite numbers in the rows' spare slots (they meet zero coefficients): clear them
+            if (NKB == 1 && !LERP && lane < 32) { Yp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; Sp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; }
+        }
         bool ok = !tt.unsorted;
         double z[DT];
         bool same_k = false;                               // this surface's strikes are the previous surface's: tables (and, with a
@@ -704,7 +719,8 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
 #pragma unroll
                 for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
             }
-            if (act) dense_maturity_pass<METHOD, true, false, VAR, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp, 0, 0, nT);
+            if (act) dense_maturity_pass<METHOD, true, false, VAR, TSH>(z, tt, TSH ? TTp : TTl, TSH ? Wp : Wl, outb, 0, lane, true, mT, mK,
+                                                                        nostamp, 0, 0, nT);
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         } else if (lane == 0) {
             reinterpret_cast<unsigned long long*>(outb)[0] = D_SENTINEL;     // redone by the compaction / generic kernel (later launches)
@@ -732,7 +748,8 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR || d_is_step(p.method);
     const bool local = d_is_local(p.method);
     if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || lerp || local)) return 0;
-    if (p.t_stride != 0 || p.tq_stride != 0) return 0;
+    const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
+    if (!tsh && !(p.method == IVS_LINEAR && p.mT <= D_WLDS_MAX_MT)) return 0;
     if (p.mK > 64 || p.mT > D_MAX_MT) return 0;
     if (p.nT < 4 || p.nT > DT || p.nK < 4 || p.nK > 128) return 0;
     if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
@@ -740,9 +757,15 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     const bool fixed64 = !p.k_off && p.nK == DK && p.nT == DT && !(reinterpret_cast<uintptr_t>(p.sigma) & 15);
     if (fixed64 && p.method == IVS_AKIMA) return 0;      // 64 x 16 akima: the one-pass kernel (256 VGPRs) wins -- at 168 it spills 50 registers
     TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
-    if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
-    p.tqs = tq;
-    p.redo = tq->redo;
+    if (tsh) {
+        if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
+        p.tqs = tq;
+        p.redo = tq->redo;
+    } else {      // per-surface maturities: the T-phase runs inside the kernel; only the queue heads need zeroing
+        if (hipMemsetAsync(tq->queue, 0, sizeof(TqShared::queue), st) != hipSuccess) return -1;
+        p.tqs = nullptr;
+        p.redo = nullptr;
+    }
     p.queue = tq->queue;
     auto grid_for = [&](size_t lds, int64_t work, int wg_cap = 12) {
         int per_cu = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));     // LDS is granted in 1280-byte granules
@@ -779,9 +802,13 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
 #else
 #define IVS_PASS_LAUNCH(NKB_, VAR_, SL_, CAP, LIST)                                                                                      \
     {                                                                                                                                    \
-        const size_t lds = lerp ? pass_lds_bytes<NKB_, VAR_, SL_, 1>() : (local ? pass_lds_bytes<NKB_, VAR_, SL_, 2>() : pass_lds_bytes<NKB_, VAR_, SL_, 0>());  \
-        const int64_t grid = grid_for(lds, p.B, (local && (VAR_)) ? 8 : (CAP));            \
+        size_t lds = lerp ? pass_lds_bytes<NKB_, VAR_, SL_, 1>() : (local ? pass_lds_bytes<NKB_, VAR_, SL_, 2>() : pass_lds_bytes<NKB_, VAR_, SL_, 0>());  \
+        if (!tsh) lds += PASS_TQ_DOUBLES * 8;                                                                                            \
+        const int64_t grid = grid_for(lds, p.B, (local && (VAR_)) ? 8 : (CAP));                                                          \
         if (!(VAR_)) p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);                                                          \
+        if (!tsh) {                                                                                                                      \
+            hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, 8, false>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST);                              \
+        } else                                                                                                                           \
         switch (p.method) {                                                                                                              \
             case IVS_CUBIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;             \
             case IVS_CUBICSPLINE: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
@@ -824,7 +851,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
 #undef IVS_PASS_LAUNCH
     if (hipGetLastError() != hipSuccess) return -1;
 #ifndef IVS_DIAG_MINIMAL
-    if (fixed64 && launch_surface_masked(p, cx)) ++p.redo;   // tagged surfaces (missing quotes): the masked fast pass first ...
+    if (fixed64 && launch_surface_masked(p, cx) && p.redo) ++p.redo;   // tagged surfaces (missing quotes): the masked fast pass first ...
 #endif
     launch_surface_generic<true>(p, cx);     // ... then the generic kernel for whatever is still tagged (cheap when nothing is)
     return 1;

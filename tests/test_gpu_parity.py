@@ -361,6 +361,14 @@ def test_dense_var_per_surface_maturities(method):
     ref, rst = O.surface_batch(d["K"], Tb, d["sigma"], Kq, Tqb, METHODS[method], k_off=d["k_off"])
     assert np.array_equal(st.cpu().numpy(), rst)
     close(out.cpu().numpy(), ref, method, f"ragged per-surface T {method}")
+    # the same ragged batch with 16 query maturities per surface (weights in LDS: `linear` takes the row-pass kernels here)
+    Tq16 = np.ascontiguousarray(Tqb[:, 4:20]); Tq16[7] = np.sort(Tq16[7])
+    out, st = engine.surface_batch(dev(d["K"]), dev(Tb), dev(d["sigma"]), dev(Kq), dev(Tq16), method,
+                                   k_off=dev(d["k_off"]), nK_max=d["nK_max"], n_maturities=16)
+    assert _is_var_kernel(engine.last_kernel()), engine.last_kernel()
+    ref, rst = O.surface_batch(d["K"], Tb, d["sigma"], Kq, Tq16, METHODS[method], k_off=d["k_off"])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    close(out.cpu().numpy(), ref, method, f"ragged per-surface T, 16 query maturities {method}")
 
 
 @pytest.mark.parametrize("method", ["linear", "cubic"])
