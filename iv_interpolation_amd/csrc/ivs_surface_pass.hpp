@@ -22,8 +22,9 @@
 // per-knot tables and per-segment local slopes (pass_local_tables / pass_local_slopes).
 // Work distribution: work queues (WorkQueue, ivs_surface_generic.hpp), not static striding.
 // Scope: T and Tq shared by the batch, mK <= 64 (one block of output strikes: the pass structure would recompute the
-// slopes per block), 4..16 maturities, 4..128 strikes; 64 x 16 akima, per-surface maturities and wider output grids stay on
-// the one-pass kernels; `quadratic` on the generic kernel.
+// slopes per block), 4..16 maturities, 4..128 strikes; per-surface maturities for `linear` with mT <= 16 (TSH = false);
+// 64 x 16 akima, per-surface maturities of the other methods and wider output grids stay on the one-pass kernels;
+// `quadratic` on the generic kernel.
 #pragma once
 #include "ivs_surface_dense_var2.hpp"
 #include "ivs_surface_masked.hpp"
