@@ -51,6 +51,9 @@ __host__ __device__ constexpr bool d_is_nak(int m) { return m == IVS_CUBIC || m 
 __host__ __device__ constexpr bool d_is_local(int m) { return m == IVS_PCHIP || m == IVS_AKIMA; }          // 3-/5-point slopes
 __host__ __device__ constexpr bool d_is_hermite(int m) { return d_is_nak(m) || d_is_local(m); }
 __host__ __device__ constexpr bool d_extrap_right(int m) { return m == IVS_CUBICSPLINE || m == IVS_PCHIP; }
+// 'quadratic' (row-pass kernels only): B-spline coefficients from a tridiagonal collocation system, evaluation = 4 weights
+// over the coefficients c[j-1 .. j+2] of the data interval j (one of the outer weights is 0)
+__host__ __device__ constexpr bool d_is_quad(int m) { return m == IVS_QUADRATIC; }
 // two-knot rules without slopes besides np.interp: nearest / zero / from_derivatives (row-pass kernels only)
 __host__ __device__ constexpr bool d_is_step(int m) { return m == IVS_NEAREST || m == IVS_ZERO || m == IVS_FROM_DERIVATIVES; }
 
@@ -136,6 +139,27 @@ __device__ __forceinline__ double step_eval(double xq, double x0, double x1, dou
     const double s = (xq - x0) / (x1 - x0);
     const double a = y0 * (1.0 - s), b = y1 * s;
     return a + b;
+}
+
+// ---- 'quadratic' on the fast kernels (scipy make_interp_spline(k = 2); knots and basis: quad_knot / quad_basis, ivs_device.hpp)
+// collocation row of site i on n sites X: lo c_{i-1} + di c_i + up c_{i+1} = y_i (rows 0 and n-1: c_i = y_i)
+template <class XA>
+__device__ __forceinline__ void quad_row(const XA& x, int n, int i, double& lo, double& di, double& up) {
+    lo = 0.0; di = 1.0; up = 0.0;
+    if (i > 0 && i < n - 1) quad_basis(x, n, i + 1, x(i), lo, di, up);
+}
+// evaluation at xq in the data interval jj (= min(find_interval, n - 2); the caller handles outside-the-hull): weights of
+// c[jj-1], c[jj], c[jj+1], c[jj+2] -- eval_quadratic's window [q, q+2] is [jj-1, jj+1] or [jj, jj+2]
+template <class XA>
+__device__ __forceinline__ void quad_weights(const XA& x, int n, int j, double xq, double& a0, double& a1, double& a2, double& a3) {
+#pragma clang fp contract(off)
+    const int jj = j > n - 2 ? n - 2 : j;
+    int q = n - 3;
+    if (j < n - 1) { q = j - 1 + ((xq >= (x(j + 1) + x(j)) / 2.0) ? 1 : 0); q = q < 0 ? 0 : (q > n - 3 ? n - 3 : q); }
+    double h0, h1, h2;
+    quad_basis(x, n, q + 2, xq, h0, h1, h2);
+    const bool lowwin = q < jj;                          // window starts at jj - 1
+    a0 = lowwin ? h0 : 0.0; a1 = lowwin ? h1 : h0; a2 = lowwin ? h2 : h1; a3 = lowwin ? 0.0 : h2;
 }
 
 // Inclusive scan over lanes 0..N-1 (N = 16 or 64) of 2x2 matrix products P_i <- P_i * P_{i-1} * ... * P_0.
@@ -605,7 +629,21 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
         tt.pm_last = SC[288 + nT - 1];
         __syncthreads();
     }
-    if (!d_is_hermite(METHOD) && lane < DT) {          // lerp methods: {T_j, T_j+1, 1/dt, dt} per interval
+    if (d_is_quad(METHOD)) {       // once per call (tq_tables_kernel): lane 0 eliminates the 16-knot collocation system serially
+        if (lane == 0) {
+            const CView tx{Tsh, 1};
+            double cprev = 0.0;
+            for (int i = 0; i < DT; ++i) {
+                double lo = 0.0, di = 1.0, up = 0.0;
+                if (i < nT) quad_row(tx, nT, i, lo, di, up);
+                const double rw = 1.0 / (di - lo * cprev);
+                cprev = up * rw;
+                TT[i * 4 + 0] = i < nT ? rw : 0.0; TT[i * 4 + 1] = 0.0; TT[i * 4 + 2] = i < nT ? lo * rw : 0.0; TT[i * 4 + 3] = i < nT ? cprev : 0.0;
+            }
+        }
+        __syncthreads();
+    }
+    if (!d_is_hermite(METHOD) && !d_is_quad(METHOD) && lane < DT) {          // lerp methods: {T_j, T_j+1, 1/dt, dt} per interval
         const bool in = lane < nT - 1;
         const double t0 = in ? Tsh[lane] : 0.0, t1 = in ? Tsh[lane + 1] : 1.0;
         TT[lane * 4 + 0] = t0; TT[lane * 4 + 1] = t1; TT[lane * 4 + 2] = refined_rcp(t1 - t0); TT[lane * 4 + 3] = t1 - t0;
@@ -636,7 +674,12 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
     } else code = j;
     const int jj = code >= 0 && code <= nT - 2 ? code : 0;
     const double x0 = Tsh[jj], x1 = Tsh[jj + 1];
-    if (CUB) {
+    if (d_is_quad(METHOD)) {
+        const CView tx{Tsh, 1};
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (code >= 0 && code <= nT - 2) quad_weights(tx, nT, (x == tl) ? nT - 1 : code, x, a0, a1, a2, a3);
+        tt.w0 = a0; tt.w1 = a1; tt.w2 = a2; tt.w3 = a3;
+    } else if (CUB) {
         const double h = x1 - x0, u = x - x0, t = u / h, omt = 1.0 - t;
         tt.w0 = (1.0 + 2.0 * t) * omt * omt;              // h00
         tt.w1 = t * t * (3.0 - 2.0 * t);                  // h01
@@ -678,8 +721,10 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                                                     int mK, StampFn&& stamp, int row_lo = 0, int row_hi = 0,
                                                     int nT_rt = DT) {
     const int nT = NTR ? nT_rt : DT;
-    constexpr bool CUB = d_is_hermite(METHOD);
+    constexpr bool QUAD = d_is_quad(METHOD);
+    constexpr bool CUB = d_is_hermite(METHOD) || QUAD;
     static_assert(!d_is_step(METHOD) || WLDS, "nearest / zero / from_derivatives: per-row weights only");
+    static_assert(!QUAD || SM, "quadratic: batch-wide maturity tables only");
     constexpr bool w_lds = WLDS && !SM;
     const double nanv = __builtin_nan("");
     const cdptr cTT = to_const(TT), cW = to_const(W);          // SM only
@@ -763,7 +808,9 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
 #pragma unroll
                 for (int u = 0; u < SMG; ++u) {
                     const int i = SMG * h + u;
-                    if (!NTR) {
+                    if (QUAD) {      // collocation system: right-hand side = the value itself (PP = 1 / pivot; all-zero rows beyond nT)
+                        prev = pp[u] * z[i] - al[u] * prev;
+                    } else if (!NTR) {
                         const int ia = i == 0 ? 0 : (i == DT - 1 ? DT - 3 : i - 1), ib = i == 0 ? 1 : (i == DT - 1 ? DT - 2 : i);
                         const double dA = z[ia + 1] - z[ia], dB = z[ib + 1] - z[ib];
                         prev = (pp[u] * dA + qq[u] * dB) - al[u] * prev;
@@ -832,7 +879,8 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
                 if (!mine(tq)) continue;
                 double a0, a1, a2, a3;
                 weights(tq, a0, a1, a2, a3);
-                put(tq, a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1]);
+                if (QUAD) put(tq, a0 * s[jv > 0 ? jv - 1 : 0] + a1 * s[jv] + a2 * s[jv + 1] + a3 * s[jv + 2 < DT ? jv + 2 : DT - 1]);
+                else put(tq, a0 * z[jv] + a1 * z[jv + 1] + a2 * s[jv] + a3 * s[jv + 1]);
             }
         }
     } else {
@@ -922,6 +970,7 @@ inline void launch_tq_tables(const SurfaceParams& p, TqShared* o, hipStream_t st
     switch (p.method) {
         IVS_TQ_CASE(IVS_LINEAR) IVS_TQ_CASE(IVS_CUBIC) IVS_TQ_CASE(IVS_CUBICSPLINE) IVS_TQ_CASE(IVS_SLINEAR)
         IVS_TQ_CASE(IVS_PCHIP) IVS_TQ_CASE(IVS_AKIMA) IVS_TQ_CASE(IVS_NEAREST) IVS_TQ_CASE(IVS_ZERO) IVS_TQ_CASE(IVS_FROM_DERIVATIVES)
+        IVS_TQ_CASE(IVS_QUADRATIC)
         default: break;
     }
 #undef IVS_TQ_CASE

@@ -17,14 +17,15 @@
 // of eight neighbouring segments hit eight different bank groups; tables at segment stride 10 (b128 broadcast reads of
 // 8 or 16 segments conflict-free), the scan multipliers in the two spare slots behind each table segment.
 // 128 strikes: rows back to back (stride 128), both planes slot-swizzled over (segment >> 2).
-// Other methods on the same structure: linear / slinear / nearest / zero / from_derivatives carry no S plane and no tables
+// Other methods on the same structure: quadratic = the same solve on another tridiagonal system, B-spline coefficients in
+// the S plane, four taps c[j-1 .. j+2]; linear / slinear / nearest / zero / from_derivatives carry no S plane and no tables
 // (a pass = stage, two gathers per row, lerp_fast or step_eval); pchip / akima replace the K-phase and the sweeps by three
 // per-knot tables and per-segment local slopes (pass_local_tables / pass_local_slopes).
 // Work distribution: work queues (WorkQueue, ivs_surface_generic.hpp), not static striding.
 // Scope: T and Tq shared by the batch, mK <= 64 (one block of output strikes: the pass structure would recompute the
 // slopes per block), 4..16 maturities, 4..128 strikes; per-surface maturities for `linear` with mT <= 16 (TSH = false);
 // 64 x 16 akima, per-surface maturities of the other methods and wider output grids stay on the one-pass kernels;
-// `quadratic` on the generic kernel.
+// `quadratic` runs the not-a-knot machinery on its collocation system (QUADM / quad_weights).
 #pragma once
 #include "ivs_surface_dense_var2.hpp"
 #include "ivs_surface_masked.hpp"
@@ -111,7 +112,7 @@ __device__ __forceinline__ double seg_suffix_prod(double v, int lane) {
 // K-phase: factorisation tables of the not-a-knot system on n knots (n = KCAP when !VAR) at p_tix(k), the segment
 // products P_j = prod(-AL) / Q_j = prod(-CP) of every 8-knot segment, and from them the multipliers of the carry scans
 // (see pass_sweeps).  Ends with the tables visible to every lane.
-template <int NKB, bool VAR, int SL = 8>
+template <int NKB, bool VAR, int SL = 8, bool QUADM = false>      // QUADM: the collocation system of the quadratic B-spline instead
 __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int lane, double* TB, double* SCR = nullptr) {
     using G = PassGeom<NKB, SL>;
     constexpr int TS = G::TS;
@@ -135,6 +136,10 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
         const double rdxc = refined_rcp(dxc);
         const bool first = ir == 0, last = ir == n - 1;
         double a, b, c;
+        if (QUADM) {
+            const CView xv{X, 1};
+            quad_row(xv, n, i, a, b, c);
+        } else
         if (first) { a = 0.0; b = dxp; c = dxc + dxp; }
         else if (last) { a = dxmm + dxm; b = dxmm; c = 0.0; }
         else { a = dxc; b = 2.0 * (dxm + dxc); c = dxm; }
@@ -163,6 +168,9 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
         const double d = first ? dxc + dxp : dxmm + dxm;
         const double rd = refined_rcp(d);
         double pm = 0.0, pp, qq;
+        if (QUADM) {
+            pp = rw; qq = 0.0;                                   // right-hand side = y_i / pivot
+        } else
         if (first) {
             pp = (dxc + 2.0 * d) * dxp * rdxc * rd * rw;         // * dy_0
             qq = dxc * dxc * rdx_next * rd * rw;                 // * dy_1
@@ -222,7 +230,7 @@ __device__ __forceinline__ void pass_factor_tables(const double* X, int n, int l
 }
 
 // One pass: slopes of the RP rows staged in Yp -> Sp.  All 64 lanes; no barrier inside (the caller brackets it).
-template <int NKB, bool VAR, int SL = 8>
+template <int NKB, bool VAR, int SL = 8, bool QUADM = false>
 __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const double* TB, int lane, int n) {
     using G = PassGeom<NKB, SL>;
     constexpr int TN = G::TN, NSEG = G::NSEG, RS = G::RS, TS = G::TS;
@@ -264,7 +272,8 @@ __device__ __forceinline__ void pass_sweeps(const double* Yp, double* Sp, const 
             if (m == 0) { const double e = y[4] - y[3]; dA = s_first ? dB : dA; dB = s_first ? e : dB; }      // row 0: (dy_0, dy_1)
             if (!VAR && m == SL - 1) { dB = s_last ? dA : dB; dA = s_last ? dM : dA; }                             // row n-1: (dy_{n-3}, dy_{n-2})
             double r = (u ? tpp.y : tpp.x) * dA + (u ? tqq.y : tqq.x) * dB;
-            if (VAR) r = (m == mlast) ? __builtin_fma(pm_last, dM, r) : r;
+            if (QUADM) r = (u ? tpp.y : tpp.x) * y[m + 2];
+            else if (VAR) r = (m == mlast) ? __builtin_fma(pm_last, dM, r) : r;
             prev = r - (u ? tal.y : tal.x) * prev;
             d[m] = prev;
         }
@@ -473,7 +482,8 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
     constexpr bool STEP = d_is_step(METHOD);                                   // nearest / zero / from_derivatives
     constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR || STEP;     // no slopes: only the Y plane and the strikes live in LDS
     constexpr bool LOCAL = d_is_local(METHOD);                                  // pchip / akima: three tables instead of six, no sweeps
-    static_assert(LERP || LOCAL || METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "methods of the dense kernels");
+    constexpr bool QUADK = d_is_quad(METHOD);                                   // quadratic B-spline: the not-a-knot machinery on another system
+    static_assert(LERP || LOCAL || QUADK || METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "methods of the dense kernels");
     static_assert(!LOCAL || SL == 8, "local slopes are cut for 8-knot segments");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -632,7 +642,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
             if (ok) {
                 if (ps == 0 && !same_k) {
                     if (LOCAL) pass_local_tables<NKB, VAR>(Ksh, n, lane, TB);
-                    else if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL>(Ksh, n, lane, TB, Sp + KCAP);
+                    else if (!LERP && ABL != 1 && ABL != 6) pass_factor_tables<NKB, VAR, SL, QUADK>(Ksh, n, lane, TB, Sp + KCAP);
                 }
                 if (ps == 0 && !(same_k && kq_shared)) {
                     // ---- strike search + weights of this lane's output strike (once per strike grid / query grid)
@@ -650,6 +660,10 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                         l_hold = l_right && (METHOD == IVS_LINEAR || xq == xl);
                         w0 = x0; w1 = x1; w2 = x1 - x0; w3 = refined_rcp(w2);
                         l_slow = !STEP && !div_safe(w2);
+                    } else if (QUADK) {      // weights of the coefficients c[jj-1 .. jj+2]
+                        const CView kx{Ksh, 1};
+                        quad_weights(kx, n, j, xq, w0, w1, w2, w3);
+                        if (left || !(xq <= xl)) w0 = nanv;
                     } else {
                         const bool okq = !left && ((xq <= xl) || d_extrap_right(METHOD));
                         const double u = xq - x0, t = u * refined_rcp(x1 - x0), omt = 1.0 - t;
@@ -688,7 +702,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                     continue;
                 }
                 if (LOCAL) pass_local_slopes<METHOD, NKB, VAR>(Yp, Sp, TB, lane, n);
-                else if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL>(Yp, Sp, TB, lane, n);
+                else if (ABL != 1 && ABL != 6) pass_sweeps<NKB, VAR, SL, QUADK>(Yp, Sp, TB, lane, n);
                 __syncthreads();
                 // ---- strike evaluation of the pass's rows (q-lane), gathers pipelined LA rows ahead
                 if (ABL == 2 || ABL == 6) {
@@ -698,16 +712,20 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                 }
                 constexpr int LA = RP < 4 ? RP - 1 : 3;
                 double g0[4], g1[4], g2[4], g3[4];
+                // operands of the four weights: (y_j, y_j+1, s_j, s_j+1), or for the quadratic spline the coefficients c[jj-1 .. jj+2]
+                const double* PA = QUADK ? Sp : Yp;
+                const int a0i = QUADK ? p_swz<SL, NKB>(jj > 0 ? jj - 1 : 0) : o0, a1i = QUADK ? q0 : o1;
+                const int b0i = QUADK ? q1 : q0, b1i = QUADK ? p_swz<SL, NKB>(jj + 2 < KCAP ? jj + 2 : KCAP - 1) : q1;
 #pragma unroll
                 for (int r = 0; r < LA; ++r) {
-                    g0[r] = Yp[r * RS + o0]; g1[r] = Yp[r * RS + o1]; g2[r] = Sp[r * RS + q0]; g3[r] = Sp[r * RS + q1];
+                    g0[r] = PA[r * RS + a0i]; g1[r] = PA[r * RS + a1i]; g2[r] = Sp[r * RS + b0i]; g3[r] = Sp[r * RS + b1i];
                 }
 #pragma unroll
                 for (int r = 0; r < RP; ++r) {
                     if (r + LA < RP) {
                         const int nn = r + LA;
-                        g0[nn & 3] = Yp[nn * RS + o0]; g1[nn & 3] = Yp[nn * RS + o1];
-                        g2[nn & 3] = Sp[nn * RS + q0]; g3[nn & 3] = Sp[nn * RS + q1];
+                        g0[nn & 3] = PA[nn * RS + a0i]; g1[nn & 3] = PA[nn * RS + a1i];
+                        g2[nn & 3] = Sp[nn * RS + b0i]; g3[nn & 3] = Sp[nn * RS + b1i];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     z[ps * RP + r] = w0 * g0[r & 3] + w1 * g1[r & 3] + w2 * g2[r & 3] + w3 * g3[r & 3];
@@ -748,7 +766,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     hipStream_t st = cx.st;
     const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR || d_is_step(p.method);
     const bool local = d_is_local(p.method);
-    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || lerp || local)) return 0;
+    if (!(p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE || p.method == IVS_QUADRATIC || lerp || local)) return 0;
     const bool tsh = p.t_stride == 0 && p.tq_stride == 0;
     if (!tsh && !(p.method == IVS_LINEAR && p.mT <= D_WLDS_MAX_MT)) return 0;
     if (p.mK > 64 || p.mT > D_MAX_MT) return 0;
@@ -778,17 +796,19 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         return g > work ? work : g;
     };
     const VarList none{nullptr, nullptr};
-    static const char* const names[2][9] = {
+    static const char* const names[2][10] = {
         {"surface_pass_kernel<cubic>", "surface_pass_kernel<cubicspline>", "surface_pass_kernel<linear>", "surface_pass_kernel<slinear>",
          "surface_pass_kernel<pchip>", "surface_pass_kernel<akima>", "surface_pass_kernel<nearest>", "surface_pass_kernel<zero>",
-         "surface_pass_kernel<from_derivatives>"},
+         "surface_pass_kernel<from_derivatives>", "surface_pass_kernel<quadratic>"},
         {"surface_pass_var_kernel<cubic>", "surface_pass_var_kernel<cubicspline>", "surface_pass_var_kernel<linear>",
          "surface_pass_var_kernel<slinear>", "surface_pass_var_kernel<pchip>", "surface_pass_var_kernel<akima>",
-         "surface_pass_var_kernel<nearest>", "surface_pass_var_kernel<zero>", "surface_pass_var_kernel<from_derivatives>"}};
+         "surface_pass_var_kernel<nearest>", "surface_pass_var_kernel<zero>", "surface_pass_var_kernel<from_derivatives>",
+         "surface_pass_var_kernel<quadratic>"}};
     int mi = 0;
     switch (p.method) {
         case IVS_CUBIC: mi = 0; break; case IVS_CUBICSPLINE: mi = 1; break; case IVS_LINEAR: mi = 2; break; case IVS_SLINEAR: mi = 3; break;
         case IVS_PCHIP: mi = 4; break; case IVS_AKIMA: mi = 5; break; case IVS_NEAREST: mi = 6; break; case IVS_ZERO: mi = 7; break;
+        case IVS_QUADRATIC: mi = 9; break;
         default: mi = 8; break;
     }
     // one launch of surface_pass_kernel<method, NKB, VAR, SL> over `list`; the lerp methods carry no S plane and no tables
@@ -817,6 +837,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
             case IVS_NEAREST: hipLaunchKernelGGL((surface_pass_kernel<IVS_NEAREST, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;         \
             case IVS_ZERO: hipLaunchKernelGGL((surface_pass_kernel<IVS_ZERO, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
             case IVS_FROM_DERIVATIVES: hipLaunchKernelGGL((surface_pass_kernel<IVS_FROM_DERIVATIVES, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
+            case IVS_QUADRATIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_QUADRATIC, NKB_, VAR_, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;       \
             case IVS_PCHIP: hipLaunchKernelGGL((surface_pass_kernel<IVS_PCHIP, NKB_, VAR_, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
             case IVS_AKIMA: launch_pass_akima<NKB_, VAR_>(grid, lds, st, p, LIST); break;                                                \
             default: hipLaunchKernelGGL((surface_pass_kernel<IVS_SLINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;                  \
