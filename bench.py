@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--method", default="cubic", choices=["linear", "cubic", "cubicspline", "slinear", "pchip", "akima"])
+    ap.add_argument("--method", default="cubic", choices=["linear", "cubic", "cubicspline", "slinear", "pchip", "akima", "nearest", "zero", "from_derivatives", "quadratic"])
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1_000_000,
                     help="surfaces of the job (strong scaling: split over the ranks) or per GPU (weak scaling)")

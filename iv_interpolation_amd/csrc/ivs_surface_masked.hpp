@@ -52,10 +52,11 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 
 template <int METHOD>
-__global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR) ? 3 : 2) void surface_masked_kernel(SurfaceParams p) {
+__global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR || d_is_step(METHOD)) ? 3 : 2) void surface_masked_kernel(SurfaceParams p) {
     constexpr bool NAK = METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE;
     constexpr bool LOCAL = d_is_local(METHOD);
-    constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR;
+    constexpr bool STEP = d_is_step(METHOD);                      // nearest / zero / from_derivatives: no per-knot table either
+    constexpr bool LERP = METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR || STEP;
     static_assert(NAK || LOCAL || LERP, "methods of the dense kernels only");
     constexpr int MINROW = NAK ? 4 : (METHOD == IVS_AKIMA ? 3 : 2);      // fewer quotes in a row: the generic kernel's business
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR)
     const int mT = p.mT, mK = p.mK;
     double* YC = reinterpret_cast<double*>(smem);
     double* SS = YC + DT * MK_RS;                      // not carved for the lerp methods (never touched)
-    double* Ksh = YC + (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR ? 1 : 2) * DT * MK_RS;
+    double* Ksh = YC + (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR || d_is_step(METHOD) ? 1 : 2) * DT * MK_RS;
     uint8_t* IDX = reinterpret_cast<uint8_t*>(Ksh + DK);
     uint8_t* RANK = IDX + DT * DK;
     int* NROW = reinterpret_cast<int*>(RANK + DT * DK);
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR)
             const int j = jf >= 0 ? (int)RANK[t * DK + jf] - 1 : -1;
             const MaskedX X{Ksh, IDX + t * DK};
             const CView Y{YC + t * MK_RS, 1}, S{SS + t * MK_RS, 1};
-            if (LERP) z[t] = eval_linear(X, Y, n, j, xq, METHOD == IVS_LINEAR);
+            if (STEP) z[t] = eval_method(METHOD, X, Y, S, n, j, xq);
+            else if (LERP) z[t] = eval_linear(X, Y, n, j, xq, METHOD == IVS_LINEAR);
             else z[t] = eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
             all_ok = all_ok && !__builtin_isnan(z[t]);
         }
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR)
 inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
     if (p.k_off || p.nK != DK || p.nT != DT || p.mK > 64 || p.mT > D_MAX_MT) return false;
     if (p.t_stride != 0 || p.tq_stride != 0 || !p.tqs) return false;
-    const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR;
+    const bool lerp = p.method == IVS_LINEAR || p.method == IVS_SLINEAR || d_is_step(p.method);
     const size_t lds = masked_lds_bytes(lerp);
     int64_t grid = (int64_t)cx.num_cu * (lerp ? 12 : 8);
     const int64_t work = (p.B + 63) / 64;
@@ -320,7 +322,8 @@ inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
     switch (p.method) {
 #define IVS_MASKED_CASE(M) case M: hipLaunchKernelGGL((surface_masked_kernel<M>), dim3((unsigned)grid), dim3(64), lds, cx.st, p); break;
         IVS_MASKED_CASE(IVS_LINEAR) IVS_MASKED_CASE(IVS_SLINEAR) IVS_MASKED_CASE(IVS_CUBIC) IVS_MASKED_CASE(IVS_CUBICSPLINE)
-        IVS_MASKED_CASE(IVS_PCHIP) IVS_MASKED_CASE(IVS_AKIMA)
+        IVS_MASKED_CASE(IVS_PCHIP) IVS_MASKED_CASE(IVS_AKIMA) IVS_MASKED_CASE(IVS_NEAREST) IVS_MASKED_CASE(IVS_ZERO)
+        IVS_MASKED_CASE(IVS_FROM_DERIVATIVES)
 #undef IVS_MASKED_CASE
         default: return false;
     }
