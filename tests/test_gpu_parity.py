@@ -772,3 +772,32 @@ def test_repeated_strike_grids_reuse_the_tables(method):
     ref3, rst3 = O.surface_batch(Kr, d["T"], sg, Kq, Tq, METHODS[method], k_off=off)
     assert np.array_equal(st3.cpu().numpy(), rst3)
     close(out.cpu().numpy(), ref3, method, f"ragged with repeated strikes {method}")
+
+
+def test_overlapping_calls_on_two_streams_with_their_own_workspaces():
+    """include/ivs.h: calls that may overlap in time need distinct workspaces (maturity tables, work-queue heads, redo flags
+    live there); with them, two streams can run different batches and methods at once."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    Kq, Tq = synth.query_grids(64, 16)
+    Kq, Tq = dev(Kq), dev(Tq)
+    B = 60000
+    d1 = synth.torch_batch(B, 64, 16, seed=synth.BASE_SEED + 80)
+    d2 = synth.torch_ragged_batch(B // 4, 16, 8, 128, seed=synth.BASE_SEED + 81)
+    kw2 = dict(k_off=d2["k_off"], nK_max=128, n_maturities=16)
+    ref1, _ = engine.surface_batch(d1["K"], d1["T"], d1["sigma"], Kq, Tq, "cubic")
+    ref2, _ = engine.surface_batch(d2["K"], d2["T"], d2["sigma"], Kq, Tq, "pchip", **kw2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1 = torch.empty_like(ref1); o2 = torch.empty_like(ref2)
+    st1 = torch.empty((B,), dtype=torch.int32, device="cuda"); st2 = torch.empty((B // 4,), dtype=torch.int32, device="cuda")
+    w1 = engine.surface_workspace(B, False); w2 = engine.surface_workspace(B // 4, True)
+    for rep in range(5):
+        o1.fill_(float("nan")); o2.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            engine.surface_batch(d1["K"], d1["T"], d1["sigma"], Kq, Tq, "cubic", out=o1, status=st1, workspace=w1)
+        with torch.cuda.stream(s2):
+            engine.surface_batch(d2["K"], d2["T"], d2["sigma"], Kq, Tq, "pchip", out=o2, status=st2, workspace=w2, **kw2)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, ref1) and torch.equal(o2, ref2), rep
