@@ -501,7 +501,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
     // T-phase runs per surface into LDS tables of its own (TT, W: 1 KB behind everything else), scratch = the planes, which
     // are free between two surfaces; mT <= 16 (weights in LDS).  Shipped for `linear` only: the not-a-knot instantiations hold
     // the solve tables in VGPRs (no scalar cache without batch-wide tables), spilled 70-80 registers and ran at 153 instead of
-    // the one-pass kernel's 242 M surfaces/s.
+    // the one-pass kernel's 242 M surfaces/s; at 2 wavefronts per SIMD (no scratch) they reach 227 M -- still behind it.
     static_assert(TSH || METHOD == IVS_LINEAR, "per-surface maturities: linear only (the not-a-knot instantiations spilled 70-80 registers)");
     double* TTl = (LERP ? Ksh + KCAP : (RUNP ? TB + 4 * TN + 2 : Ksh + KCAP));
     double* Wl = TTl + DT * 4;
@@ -589,7 +589,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
             __syncthreads();                                   // the previous surface is done with the planes and with TT / W
             dense_t_phase<METHOD, true, VAR>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, LERP ? Yp : Yp + 600, TTl, Wl, tt, nT, Yp);
             // the scratch may leave non-finite numbers in the rows' spare slots (they meet zero coefficients): clear them
-            if (NKB == 1 && !LERP && lane < 32) { Yp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; Sp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; }
+            if (NKB == 1 && !LERP && lane < 2 * RP) { Yp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; Sp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; }
         }
         bool ok = !tt.unsorted;
         double z[DT];
