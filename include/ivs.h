@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IVS_ABI_VERSION 2
+#define IVS_ABI_VERSION 3
 
 /* interpolation methods: the pandas method names that core.py:61 forwards
  * (`merged[col].interpolate(method=self.method)`) and that this engine implements */
@@ -44,10 +44,16 @@ enum {
     IVS_QUADRATIC   = 9, /* 'quadratic': interp1d(kind=2) = make_interp_spline(k=2), knots at the midpoints of the sites; NaN outside; >= 3 */
     IVS_BARYCENTRIC = 10,/* 'barycentric': scipy barycentric_interpolate, ONE polynomial through all valid knots; NaN left of the
                             first knot, the polynomial continues on the right; 1..IVS_POLY_MAX_KNOTS knots; 1-D kernels only */
-    IVS_KROGH       = 11 /* 'krogh': scipy krogh_interpolate, the same polynomial in Newton form (divided differences); 1-D only */
+    IVS_KROGH       = 11,/* 'krogh': scipy krogh_interpolate, the same polynomial in Newton form (divided differences); 1-D only */
+    IVS_PAD         = 12,/* 'pad' / 'ffill': pandas pad_or_backfill forward (core.py:61 forwards the name; pandas 2.x still runs
+                            it, with a FutureWarning): the last valid knot at or before the row; NaN left of the first knot,
+                            hold-last on the right; never raises (>= 0 knots) */
+    IVS_BFILL       = 13 /* 'bfill' / 'backfill': the mirror -- the first valid knot at or after the row; NaN right of the last
+                            knot, the first knot's value on the left */
 };
 #define IVS_POLY_MAX_KNOTS 32   /* above this the reference's own polynomial is numerical noise: IVS_ST_ILL_CONDITIONED */
-/* methods 0-3, 6, 7 run on the dense fast kernels; 4, 5, 8, 9 on the generic surface kernel; 0-11 on the 1-D kernels */
+/* surfaces: methods 0-9 run on the fast (row-pass / one-pass / masked) kernels, 12 and 13 on the generic surface kernel,
+ * 10 and 11 are rejected (EINVAL); the 1-D kernels take all of 0-13 */
 
 /* return codes */
 enum {
@@ -158,7 +164,10 @@ int ivs_frame_rows(const int64_t* q_off, int64_t n_series, int64_t total_queries
  *
  *   K      strikes.  k_off == NULL: surface b at K + b*k_stride (k_stride 0 = one shared grid), nK each.
  *                    k_off != NULL: ragged, surface b has k_off[b+1]-k_off[b] strikes at K + k_off[b];
- *                                   nK is then the maximum count in the batch.
+ *                                   nK is then the maximum count in the batch and k_stride the TOTAL number of strikes
+ *                                   K holds (sigma: nT times that): a surface whose span is negative, exceeds nK or
+ *                                   leaves [0, k_stride] gets IVS_ST_BAD_SHAPE and is skipped -- no host-side validation
+ *                                   of the offsets is needed (0 = total unknown: only the span is checked).
  *   T      maturities of surface b at T + b*t_stride (0 = shared), nT each (nT <= 32)
  *   sigma  surface b at sigma + nT*nK*b (uniform) or sigma + nT*k_off[b] (ragged); [nT][nK_b] row-major
  *   Kq/Tq  query grids of surface b at Kq + b*kq_stride / Tq + b*tq_stride (0 = shared), mK / mT points

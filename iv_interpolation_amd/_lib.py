@@ -21,18 +21,31 @@ def flag_map_groups(n: int) -> int:
     """IVS_FLAG_MAP_GROUPS(n): tuning override of the 64x16 kernel's surface -> workgroup mapping (0 = default)."""
     return (int(n) & 0xff) << 8
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # pandas method names (reference core.py:61 forwards self.method) -> engine codes
 NEAREST, ZERO, PCHIP, AKIMA, FROM_DERIVATIVES = 4, 5, 6, 7, 8
 QUADRATIC = 9
 BARYCENTRIC, KROGH = 10, 11
+PAD, BFILL = 12, 13        # pandas' fill methods, which Series.interpolate still executes (pad_or_backfill)
 POLY_MAX_KNOTS = 32
 METHOD_CODES = {"linear": LINEAR, "index": LINEAR, "values": LINEAR,
                 "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
                 "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
                 "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES, "quadratic": QUADRATIC,
-                "barycentric": BARYCENTRIC, "krogh": KROGH}
+                "barycentric": BARYCENTRIC, "krogh": KROGH,
+                "pad": PAD, "ffill": PAD, "bfill": BFILL, "backfill": BFILL}
+
+
+def method_code(name) -> int:
+    """Engine code of a pandas method name, or KeyError.  pandas matches the FILL methods case-insensitively
+    (`method.lower() in fillna_methods`, verified against the reference: 'PAD', 'Backfill' work) and every other name
+    exactly ('Linear' raises -> None)."""
+    if name in METHOD_CODES:
+        return METHOD_CODES[name]
+    if isinstance(name, str) and name.lower() in ("pad", "ffill", "bfill", "backfill"):
+        return METHOD_CODES[name.lower()]
+    raise KeyError(name)
 
 
 class EngineUnavailable(RuntimeError):

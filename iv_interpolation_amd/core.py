@@ -22,7 +22,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import pandas as pd
 
-from ._lib import METHOD_CODES, POLY_MAX_KNOTS, ST_ILL_CONDITIONED, ST_OK, EngineUnavailable
+from ._lib import BFILL, METHOD_CODES, PAD, method_code, POLY_MAX_KNOTS, ST_ILL_CONDITIONED, ST_OK, EngineUnavailable
 
 logger = logging.getLogger("interpolation.core")   # the reference's logger name (core.py:7)
 
@@ -37,19 +37,40 @@ GREEK_COLS = ["delta", "gamma", "theta", "vega", "rho"]                         
 _PANDAS_METHODS = ["linear", "time", "index", "values", "nearest", "zero", "slinear", "quadratic", "cubic",
                    "barycentric", "krogh", "spline", "polynomial", "from_derivatives", "piecewise_polynomial",
                    "pchip", "akima", "cubicspline"]
+# 'pad' / 'ffill' / 'bfill' / 'backfill': Series.interpolate still runs pandas' fill methods (pad_or_backfill, with a
+# FutureWarning) -- and, unlike the interpolation methods, fills OBJECT columns too and then soft-converts them
+_FILL_METHOD_CODES = (PAD, BFILL)
 
 
-def _chan_kind(col: pd.Series) -> str:
+def _chan_kind(col: pd.Series, fill_method: bool = False) -> str:
     """How pandas' Series.interpolate treats a numeric channel of this dtype (reference core.py:61; verified against the
-    real reference, golden cases t1/t2/t3): 'obj' = object dtype: interpolate is a (deprecated) no-op, the column keeps
-    its source cells; 'f32' = float32: computed in float64 from the upcast knots, stored as float32; 'ext' = nullable
-    Float64 / Float32: result keeps the extension dtype; 'f64' = everything else (float64, ints: existing rules)."""
+    real reference, golden cases t1/t2/t3/z*): 'obj' = object dtype: interpolate is a (deprecated) no-op, the column keeps
+    its source cells -- except under the fill methods ('objfill'): pad_or_backfill fills object cells like any other and
+    soft-converts the result (all floats -> float64); 'f32' = float32: computed in float64 from the upcast knots, stored
+    as float32; 'ext' = nullable Float64 / Float32: result keeps the extension dtype; 'f64' = everything else (float64,
+    ints: existing rules)."""
     dt = col.dtype
     if dt == object:
-        return "obj"
+        return "objfill" if fill_method else "obj"
     if isinstance(dt, pd.api.extensions.ExtensionDtype):
         return "ext" if str(dt) in ("Float64", "Float32") else "f64"
     return "f32" if dt == np.float32 else "f64"
+
+
+def _objfill_source(cells: np.ndarray) -> np.ndarray:
+    """Object channel under a fill method: the device fills ROW NUMBERS (exact in float64) instead of values -- the
+    arithmetic-free fill rule is the same, and the host then takes the object cells through the filled numbers."""
+    return np.where(np.asarray(pd.isna(cells)), np.nan, np.arange(len(cells), dtype=np.float64))
+
+
+def _objfill_finish(filled_rows: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """Filled row numbers -> object cells, then pandas' soft conversion of a filled object block (Block._maybe_downcast
+    -> Block.convert -> lib.maybe_convert_objects: all floats become float64, strings stay object)."""
+    miss = np.isnan(filled_rows)
+    col = np.empty(len(filled_rows), dtype=object)
+    col[:] = np.nan
+    col[~miss] = cells[filled_rows[~miss].astype(np.int64)]
+    return pd.Series(col, dtype=object).infer_objects().to_numpy()
 
 
 def _chan_finish(values: np.ndarray, kind: str, dtype):
@@ -245,7 +266,7 @@ class IVInterpolator:
         if not live:
             return results
         be = self._backend or HipBackend()
-        code = METHOD_CODES[self.method]
+        code = method_code(self.method)
         # ---- pack (CSR over symbols)
         ps = [preps[i] for i in live]
         n_src = np.array([len(p.pos) for p in ps], np.int64)
@@ -297,9 +318,10 @@ class IVInterpolator:
         for c in ["date"] + REQUIRED:
             if c not in data.columns:
                 raise KeyError(c)
-        if self.method not in METHOD_CODES:
-            raise ValueError(f"method '{self.method}' is not implemented by the MI355X engine")
-        code = METHOD_CODES[self.method]
+        try:
+            code = method_code(self.method)
+        except KeyError:
+            raise ValueError(f"method '{self.method}' is not implemented by the MI355X engine") from None
         be = self._backend or HipBackend()
         if data["date"].dtype == object:
             # string dates: the reference sorts them LEXICOGRAPHICALLY before parsing (core.py:32-33); that order is a
@@ -307,6 +329,10 @@ class IVInterpolator:
             parts = [r for r in self.interpolate_batch([g for _, g in data.groupby("symbol", sort=True)]) if r is not None]
             if parts:
                 return pd.concat(parts, ignore_index=True)
+            cols_e = ["date"] + [c for c in data.columns if c != "date"]
+            cols_e += [] if "is_interpolated" in cols_e else ["is_interpolated"]
+            return pd.DataFrame({c: pd.Series(dtype=("datetime64[ns]" if c == "date" else bool if c == "is_interpolated"
+                                                     else data[c].dtype)) for c in cols_e})
         cols_in = [c for c in data.columns if c != "date"]
         out_cols = ["date"] + cols_in + (["is_interpolated"] if "is_interpolated" not in cols_in else [])
         d_idx = pd.DatetimeIndex(pd.to_datetime(data["date"]))
@@ -368,8 +394,10 @@ class IVInterpolator:
         total_q = int(q_off[-1])
         src_rows = rows[ridx]                                            # positions in `data` of the on-lattice rows
         # ---- channels
-        kinds = [_chan_kind(data[c]) for c in NUMERIC_COLS]
-        chan = [np.zeros(len(src_rows)) if k == "obj" else data[c].to_numpy(dtype=np.float64, na_value=np.nan)[src_rows]
+        kinds = [_chan_kind(data[c], code in _FILL_METHOD_CODES) for c in NUMERIC_COLS]
+        chan = [np.zeros(len(src_rows)) if k == "obj" else
+                _objfill_source(data[c].to_numpy()[src_rows]) if k == "objfill" else
+                data[c].to_numpy(dtype=np.float64, na_value=np.nan)[src_rows]
                 for c, k in zip(NUMERIC_COLS, kinds)]
         nan_cnt = np.stack([np.add.reduceat(np.isnan(v).astype(np.int64), src_off[:-1]) for v in chan], 1) + (M - q)[:, None]
         needs = (nan_cnt > 0) & (nan_cnt < M[:, None])                   # pandas leaves all-NaN / no-NaN columns alone
@@ -438,6 +466,9 @@ class IVInterpolator:
                     merged[gpos] = v
                     cols[name] = merged
                     continue
+                if kinds[ci] == "objfill":                               # the channel carried row numbers of `v`
+                    cols[name] = _objfill_finish(out[ci], v)
+                    continue
                 merged = out[ci]                                         # knots keep their cells, the rest is interpolated
                 # (a column pandas leaves alone -- no NaN at all, or nothing but NaN -- comes back as its own cells)
                 if nothing_missing and int_dtype is not None:
@@ -474,8 +505,10 @@ class IVInterpolator:
                 keep &= ~np.asarray(pd.isna(cols[c]))
         cols["is_interpolated"] = sym_na
         if greeks is not None:
+            # a channel pandas does not compute on (object dtype) gives the epilogue nothing to work from: undefined -> NaN
+            undefined = any(k in ("obj", "objfill") for k in kinds)
             for gi, gname in enumerate(GREEK_COLS):
-                cols[gname] = greeks[gi]
+                cols[gname] = np.full(total_q, np.nan) if undefined else greeks[gi]
                 if gname not in out_cols:
                     out_cols.append(gname)
         res = pd.DataFrame({c: cols[c] for c in out_cols}, copy=False)
@@ -499,7 +532,11 @@ class IVInterpolator:
         if len(timeline) > 100000:                                       # core.py:49-51
             logger.warning(f"Timeline too long: {len(timeline)} minutes")
             return None
-        if self.method not in METHOD_CODES:
+        try:
+            code = method_code(self.method)
+        except KeyError:
+            code = None
+        if code is None:
             if self.method not in _PANDAS_METHODS:
                 raise ValueError(f"method must be one of {_PANDAS_METHODS}. Got '{self.method}' instead.")
             if self.method == "time":
@@ -542,12 +579,13 @@ class IVInterpolator:
             p.src_np[c] = v[rows_on]
         p.chan_src, p.chan_needs, p.chan_kind = [], [], []
         for c in NUMERIC_COLS:                                           # core.py:58-61
-            kind = _chan_kind(df[c])
+            kind = _chan_kind(df[c], code in _FILL_METHOD_CODES)
             p.chan_kind.append(kind)
             if kind == "obj":                                            # object dtype: Series.interpolate leaves it alone
                 p.chan_src.append(np.zeros(q)); p.chan_needs.append(False)
                 continue
-            v = df[c].to_numpy(dtype=np.float64, na_value=np.nan)[rows_on]
+            v = (_objfill_source(df[c].to_numpy()[rows_on]) if kind == "objfill"
+                 else df[c].to_numpy(dtype=np.float64, na_value=np.nan)[rows_on])
             p.chan_src.append(v)
             nn = int(np.isnan(v).sum()) + (M - q)                        # NaNs of the merged column
             p.chan_needs.append(0 < nn < M)                              # pandas: all-NaN / no-NaN columns are left alone
@@ -586,6 +624,9 @@ class IVInterpolator:
                 merged[p.pos] = p.chan_src[ci]
                 if p.chan_needs[ci]:
                     merged = np.where(np.isnan(merged), out[ci], merged)
+                if p.chan_kind[ci] == "objfill":                         # row numbers of the object cells
+                    cols[name] = _objfill_finish(merged, p.src_np[name])
+                    continue
                 if nothing_missing and p.int_dtype[name] is not None:    # nothing missing: int column stays int
                     merged = merged.astype(p.int_dtype[name])
                 else:
@@ -610,8 +651,10 @@ class IVInterpolator:
         if "is_interpolated" not in order:
             order.append("is_interpolated")
         if greeks is not None:
+            # a channel pandas does not compute on (object dtype) gives the epilogue nothing to work from: undefined -> NaN
+            undefined = any(k in ("obj", "objfill") for k in p.chan_kind)
             for gi, gname in enumerate(GREEK_COLS):
-                cols[gname] = greeks[gi]
+                cols[gname] = np.full(M, np.nan) if undefined else greeks[gi]
                 if gname not in order:
                     order.append(gname)
         merged = pd.DataFrame({c: cols[c] for c in order}, copy=False)

@@ -39,7 +39,7 @@ int check_launch(const char* what) {
     return IVS_OK;
 }
 
-bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_KROGH; }
+bool valid_method(int m) { return m >= IVS_LINEAR && m <= IVS_BFILL; }
 
 // CU count of the CURRENT device, cached per device index (a process may drive several devices)
 std::atomic<int> g_cu[ivs::IVS_MAX_DEV];
@@ -366,7 +366,7 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
         return fail(IVS_EINVAL, "ivs_surface_batch_f64: workspace must be 256-byte aligned");
 
     ivs::SurfaceParams p;
-    p.K = K; p.k_off = k_off; p.k_stride = k_stride; p.nK = nK;
+    p.K = K; p.k_off = k_off; p.k_stride = k_off ? 0 : k_stride; p.nK = nK; p.k_total = k_off ? k_stride : 0;
     p.T = T; p.t_stride = t_stride; p.nT = nT;
     p.sigma = sigma; p.B = B; p.map_groups = 1; p.tqs = nullptr; p.redo = nullptr; p.queue = nullptr;
     p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;

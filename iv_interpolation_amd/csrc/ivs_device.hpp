@@ -171,7 +171,7 @@ __device__ __forceinline__ bool method_extrapolates_right(int m) { return m == I
 __host__ __device__ __forceinline__ bool method_is_poly(int m) { return m == IVS_BARYCENTRIC || m == IVS_KROGH; }
 __device__ __forceinline__ int method_min_knots(int m) {
     switch (m) {
-        case IVS_LINEAR: return 0;
+        case IVS_LINEAR: case IVS_PAD: case IVS_BFILL: return 0;
         case IVS_CUBIC: return 4;
         case IVS_NEAREST: case IVS_ZERO: case IVS_BARYCENTRIC: case IVS_KROGH: return 1;
         case IVS_AKIMA: return 3;
@@ -195,6 +195,17 @@ template <class XA, class YA>
 __device__ __forceinline__ double eval_zero(const XA& x, const YA& y, int n, int j, double xq) {
     if (j < 0 || !(xq <= x(n - 1))) return qnan();
     return y(j > n - 1 ? n - 1 : j);
+}
+// 'pad' / 'ffill' and 'bfill' / 'backfill' (pandas pad_or_backfill through Series.interpolate): the last valid knot at or
+// before xq (hold-last on the right) / the first valid knot at or after xq (the first knot's value on the left)
+template <class XA, class YA>
+__device__ __forceinline__ double eval_pad(const XA& x, const YA& y, int n, int j) {
+    return j < 0 ? qnan() : y(j > n - 1 ? n - 1 : j);
+}
+template <class XA, class YA>
+__device__ __forceinline__ double eval_bfill(const XA& x, const YA& y, int n, int j, double xq) {
+    const int k = (j >= 0 && x(j) == xq) ? j : j + 1;
+    return (k < n && !__builtin_isnan(xq)) ? y(k) : qnan();
 }
 template <class XA, class YA>
 __device__ __forceinline__ double eval_bpoly_linear(const XA& x, const YA& y, int n, int j, double xq) {
@@ -379,6 +390,8 @@ __device__ __forceinline__ double eval_method(int method, const XA& x, const YA&
         case IVS_QUADRATIC: return eval_quadratic(x, s, n, j, xq);
         case IVS_BARYCENTRIC: return eval_barycentric(x, y, s, n, xq);
         case IVS_KROGH: return eval_krogh(x, s, n, xq);
+        case IVS_PAD: return eval_pad(x, y, n, j);
+        case IVS_BFILL: return eval_bfill(x, y, n, j, xq);
         default: return eval_cubic(x, y, s, n, j, xq, method_extrapolates_right(method));
     }
 }

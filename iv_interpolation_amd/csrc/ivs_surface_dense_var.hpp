@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void var_classify_kernel(SurfaceParams p, VarI
             const int64_t b = b0 + 4 * tid + k;
             const int64_t nn = ko[k + 1] - ko[k];
             cls[k] = b >= p.B ? -1 : ((nn >= 4 && nn <= 64) ? 0 : ((nn >= 65 && nn <= 128) ? 1 : 2));
-            if (cls[k] == 2 && (nn < 0 || nn > p.nK)) {         // offsets no kernel can serve (the LDS carve is sized by nK)
+            if (cls[k] >= 0 && (nn < 0 || nn > p.nK || ko[k] < 0 || (p.k_total > 0 && ko[k + 1] > p.k_total))) {
+                // offsets no kernel can serve (the LDS carve is sized by nK) or that leave the caller's K / sigma arrays
                 cls[k] = -1;
                 if (p.status) p.status[b] = IVS_ST_BAD_SHAPE;
             }

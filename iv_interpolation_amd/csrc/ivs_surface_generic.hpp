@@ -15,6 +15,7 @@ namespace ivs {
 
 struct SurfaceParams {
     const double* K; const int64_t* k_off; int64_t k_stride; int nK;
+    int64_t k_total;     // ragged batches: number of strikes K holds (k_off spans are checked against it), 0 = not checked
     const double* T; int64_t t_stride; int nT;
     const double* sigma; int64_t B;
     const double* Kq; int64_t kq_stride; int mK;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void surface_generic_kernel(SurfaceParams p) {
         if (p.k_off) {
             koff = p.k_off[b];
             const int64_t span = p.k_off[b + 1] - koff;
-            if (span < 0 || span > nKmax) {                    // wave-uniform: offsets that the LDS carve cannot hold
+            if (span < 0 || span > nKmax || koff < 0 || (p.k_total > 0 && koff + span > p.k_total)) {      // wave-uniform: offsets that the LDS carve / the caller's arrays cannot hold
                 if (p.status && lane == 0) p.status[b] = IVS_ST_BAD_SHAPE;
                 continue;
             }

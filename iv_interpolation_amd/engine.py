@@ -37,15 +37,22 @@ def _f64(torch, t, name):
     return t.contiguous()
 
 
-_ragged_ok = {}      # (data_ptr, numel, version) of k_off tensors already validated against K / sigma / nK_max
-
-
-def _check_ragged(torch, K, sigma, k_off, nK, nT):
-    """Reject CSR offsets the kernels cannot serve BEFORE anything is launched (one small device reduction + one
-    D2H read per distinct k_off tensor; the result is cached on the tensor's identity and version counter)."""
-    key = (k_off.data_ptr(), k_off.numel(), k_off._version, K.numel(), sigma.numel(), nK, nT)
-    if _ragged_ok.get("key") == key:
+def _hold_for_stream(torch, stream, *tensors):
+    """Tensors that were allocated on torch's CURRENT stream (per-call workspaces, contiguous temporaries, outputs) but are
+    read or written by kernels launched on an explicit `stream`: tell the caching allocator, so that the block is not
+    handed to the next allocation on the current stream while those kernels still run."""
+    if stream is None or stream == torch.cuda.current_stream():
         return
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(stream)
+
+
+def validate_ragged(K, sigma, k_off, nK_max: int, n_maturities: int):
+    """Optional host-side check of CSR offsets with a readable exception (one small device reduction + one D2H read, i.e. it
+    SYNCHRONISES: not for capture).  The kernels do not depend on it: they check every span against nK_max and against the
+    total strike count passed through the C ABI and flag offending surfaces with ST_BAD_SHAPE."""
+    torch = _torch()
     if k_off.numel() < 1:
         raise ValueError("k_off must hold B+1 offsets")
     span = k_off[1:] - k_off[:-1]
@@ -54,11 +61,10 @@ def _check_ragged(torch, K, sigma, k_off, nK, nT):
     first, last, smin, smax = (int(v) for v in stats)
     if first != 0 or smin < 0:
         raise ValueError("k_off must start at 0 and be non-decreasing")
-    if smax > nK:
-        raise ValueError(f"k_off: a surface has {smax} strikes but nK_max={nK}")
-    if K.numel() != last or sigma.numel() != nT * last:
-        raise ValueError(f"ragged batch: K has {K.numel()} and sigma {sigma.numel()} entries, k_off[-1]={last}, nT={nT}")
-    _ragged_ok["key"] = key
+    if smax > nK_max:
+        raise ValueError(f"k_off: a surface has {smax} strikes but nK_max={nK_max}")
+    if K.numel() != last or sigma.numel() != n_maturities * last:
+        raise ValueError(f"ragged batch: K has {K.numel()} and sigma {sigma.numel()} entries, k_off[-1]={last}, nT={n_maturities}")
 
 
 def surface_workspace(B: int, ragged: bool, device=None):
@@ -70,14 +76,17 @@ def surface_workspace(B: int, ragged: bool, device=None):
 
 def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: Optional[int] = None,
                   n_maturities: Optional[int] = None, out=None, status=None, stream=None,
-                  force_generic: bool = False, workspace=None, map_groups: int = 0, one_pass: bool = False):
+                  force_generic: bool = False, workspace=None, map_groups: int = 0, one_pass: bool = False,
+                  validate: bool = False):
     """Interpolate a batch of (strike x maturity) surfaces on the current device.
 
     Uniform: K [B,nK] or [nK] (shared), sigma [B,nT,nK].  Ragged: K flat [total], sigma flat
     [nT*total] (surface b row-major [nT][nK_b]), k_off int64 [B+1], nK_max, n_maturities.
     T [nT] or [B,nT]; Kq [mK] or [B,mK]; Tq [mT] or [B,mT].  Returns (out [B,mT,mK], status [B]).
     `workspace`: uint8 CUDA tensor from surface_workspace() (allocated per call when omitted; pass one to keep the
-    call allocation-free, e.g. under hipGraph capture).
+    call allocation-free, e.g. under hipGraph capture).  Ragged offsets are checked ON THE DEVICE (a surface whose span is
+    negative, exceeds nK_max or leaves K gets ST_BAD_SHAPE and is skipped), so the call never synchronises;
+    `validate=True` adds validate_ragged()'s host-side check (one D2H read) with a readable exception.
     """
     torch = require_device()
     lib = _lib.load()
@@ -95,8 +104,14 @@ def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: O
         if nK_max is None or n_maturities is None:
             raise ValueError("ragged batches need nK_max and n_maturities")
         k_off = k_off.contiguous()
-        B = k_off.numel() - 1; nT = int(n_maturities); nK = int(nK_max); k_stride = 0
-        _check_ragged(torch, K, sigma, k_off, nK, nT)
+        B = k_off.numel() - 1; nT = int(n_maturities); nK = int(nK_max)
+        if B < 0:
+            raise ValueError("k_off must hold B+1 offsets")
+        if sigma.numel() != nT * K.numel():
+            raise ValueError(f"ragged batch: K has {K.numel()} strikes, sigma {sigma.numel()} quotes, nT={nT}")
+        if validate:
+            validate_ragged(K, sigma, k_off, nK, nT)
+        k_stride = K.numel()       # ragged: the C ABI takes the total strike count here and bounds every span by it
     if T.shape[-1] != nT or (T.dim() == 2 and T.shape[0] != B):
         raise ValueError("T shape does not match sigma")
     t_stride = 0 if T.dim() == 1 else nT
@@ -120,6 +135,7 @@ def surface_batch(K, T, sigma, Kq, Tq, method="linear", *, k_off=None, nK_max: O
                                    _ptr(Kq), kq_stride, mK, _ptr(Tq), tq_stride, mT, _ptr(out), _ptr(status),
                                    code, flags, _ptr(workspace), workspace.numel() * workspace.element_size(),
                                    _stream(torch, stream))
+    _hold_for_stream(torch, stream, K, T, sigma, Kq, Tq, k_off, out, status, workspace)
     _lib.check(rc, "ivs_surface_batch_f64")
     return out, status
 
@@ -169,6 +185,7 @@ def interp1d_batch(xk, yk, knot_off, q_off, total_q: int, method, xq=None, strea
     rc = lib.ivs_interp1d_batch_f64(_ptr(xk), _ptr(yk), TK, _ptr(knot_off), S, Cn, TK,
                                     _ptr(xq), _ptr(q_off), total_q, _ptr(out), total_q, _ptr(status), code,
                                     _ptr(ws), ws.numel() * 8, _stream(torch, stream))
+    _hold_for_stream(torch, stream, xk, yk, out, status, ws)
     _lib.check(rc, "ivs_interp1d_batch_f64")
     return out, status
 
@@ -197,6 +214,7 @@ def interp1d_greeks_batch(xk, yk, knot_off, q_off, total_q: int, method, channel
                                            int(rows[0]), int(rows[1]), int(rows[2]), _ptr(strike_src), _ptr(rate_src),
                                            _ptr(put_src), _ptr(greeks), total_q, _ptr(ws), ws.numel() * 8,
                                            _stream(torch, stream))
+    _hold_for_stream(torch, stream, xk, yk, out, status, greeks, ws, fidx)
     _lib.check(rc, "ivs_interp1d_greeks_batch_f64")
     return out, status, greeks
 
@@ -208,8 +226,10 @@ def ffill_index_batch(src_pos, src_off, valid, q_off, total_q: int, stream=None)
     n_cols, TS = valid.shape
     S = src_off.numel() - 1
     idx = torch.empty((n_cols, total_q), dtype=torch.int32, device=valid.device)
-    rc = lib.ivs_ffill_index_batch(_ptr(src_pos), _ptr(src_off), _ptr(valid.contiguous()), TS, n_cols, _ptr(q_off),
+    valid = valid.contiguous()
+    rc = lib.ivs_ffill_index_batch(_ptr(src_pos), _ptr(src_off), _ptr(valid), TS, n_cols, _ptr(q_off),
                                    S, total_q, _ptr(idx), total_q, _stream(torch, stream))
+    _hold_for_stream(torch, stream, valid, idx)
     _lib.check(rc, "ivs_ffill_index_batch")
     return idx
 
@@ -223,7 +243,9 @@ def gather_rows(src, idx, idx_row, stream=None):
     n = idx.shape[1]
     out = torch.empty((n_cols, n), dtype=src.dtype, device=src.device)
     fn = lib.ivs_gather_rows_f64 if src.dtype == torch.float64 else lib.ivs_gather_rows_i32
-    rc = fn(_ptr(src.contiguous()), n_src, _ptr(idx), idx.shape[1], _ptr(idx_row), n_cols, n, _ptr(out), n, _stream(torch, stream))
+    src = src.contiguous()
+    rc = fn(_ptr(src), n_src, _ptr(idx), idx.shape[1], _ptr(idx_row), n_cols, n, _ptr(out), n, _stream(torch, stream))
+    _hold_for_stream(torch, stream, src, out)
     _lib.check(rc, "ivs_gather_rows")
     return out
 
@@ -236,8 +258,10 @@ def frame_rows(q_off, first_ns, chan, sym_code, status, needs, stream=None):
     Cn, total_q = chan.shape
     dates = torch.empty(total_q, dtype=torch.int64, device=chan.device)
     keep = torch.empty(total_q, dtype=torch.uint8, device=chan.device)
-    rc = lib.ivs_frame_rows(_ptr(q_off), S, total_q, _ptr(first_ns), _ptr(chan), total_q, Cn, _ptr(sym_code), _ptr(status.contiguous()),
-                            _ptr(needs.contiguous()), _ptr(dates), _ptr(keep), _stream(torch, stream))
+    status = status.contiguous(); needs = needs.contiguous()
+    rc = lib.ivs_frame_rows(_ptr(q_off), S, total_q, _ptr(first_ns), _ptr(chan), total_q, Cn, _ptr(sym_code), _ptr(status),
+                            _ptr(needs), _ptr(dates), _ptr(keep), _stream(torch, stream))
+    _hold_for_stream(torch, stream, status, needs, dates, keep)
     _lib.check(rc, "ivs_frame_rows")
     return dates, keep
 

@@ -54,6 +54,11 @@ QUADRATIC = 9    # pandas 'quadratic'  (interp1d kind=2 -> make_interp_spline(k=
 BARYCENTRIC = 10  # pandas 'barycentric' (scipy barycentric_interpolate: ONE polynomial through all valid knots;
                   #                       leading NaN kept, trailing NaN extrapolated by the polynomial, >= 1 knot)
 KROGH = 11        # pandas 'krogh'       (scipy krogh_interpolate: the same polynomial in Newton form)
+PAD = 12          # pandas 'pad' / 'ffill'   (NDFrame.interpolate -> BlockManager.pad_or_backfill, pandas/core/generic.py:
+                  #                       `if method.lower() in fillna_methods`; limit_direction defaults to 'forward'):
+                  #                       the last valid knot at or before the row; leading NaN kept, trailing held
+BFILL = 13        # pandas 'bfill' / 'backfill' (same path, limit_direction 'backward'): the first valid knot at or after
+                  #                       the row; trailing NaN kept, leading filled with the first knot
 POLY_MAX_KNOTS = 32   # beyond this the interpolating polynomial on an (almost) equispaced grid is numerical noise in
                       # the reference itself (scipy's two routes disagree at 1e-8 of the curve's scale at 32 knots, and
                       # its barycentric weights even change from run to run: random node permutation); the engine
@@ -64,7 +69,20 @@ METHOD_CODES = {
     "cubic": CUBIC, "cubicspline": CUBICSPLINE, "slinear": SLINEAR,
     "nearest": NEAREST, "zero": ZERO, "pchip": PCHIP, "akima": AKIMA,
     "from_derivatives": FROM_DERIVATIVES, "piecewise_polynomial": FROM_DERIVATIVES,
+    "pad": PAD, "ffill": PAD, "bfill": BFILL, "backfill": BFILL,
 }
+
+
+
+def method_code(name):
+    """Code of a pandas method name or None: the fill methods match case-insensitively (pandas: `method.lower() in
+    fillna_methods`), every other name exactly."""
+    if name in METHOD_CODES:
+        return METHOD_CODES[name]
+    if isinstance(name, str) and name.lower() in ("pad", "ffill", "bfill", "backfill"):
+        return METHOD_CODES[name.lower()]
+    return None
+
 
 # status codes shared with include/ivs.h
 ST_OK = 0
@@ -75,7 +93,7 @@ ST_ILL_CONDITIONED = 4 # 'barycentric' / 'krogh' with more than POLY_MAX_KNOTS v
 def min_knots(method: int) -> int:
     """Fewest valid knots the reference accepts before scipy raises."""
     return {LINEAR: 0, CUBIC: 4, CUBICSPLINE: 2, SLINEAR: 2, NEAREST: 1, ZERO: 1, PCHIP: 2, AKIMA: 3,
-            FROM_DERIVATIVES: 2, QUADRATIC: 3, BARYCENTRIC: 1, KROGH: 1}[method]
+            FROM_DERIVATIVES: 2, QUADRATIC: 3, BARYCENTRIC: 1, KROGH: 1, PAD: 0, BFILL: 0}[method]
 
 
 # --------------------------------------------------------------------------- linear
@@ -261,6 +279,24 @@ def zero_eval(xv, yv, xq):
     j = _interval(xv, xq)
     out = np.asarray(yv, np.float64)[np.clip(j, 0, xv.size - 1)]
     return np.where((j >= 0) & (xq <= xv[-1]), out, np.nan)
+
+
+def pad_eval(xv, yv, xq):
+    """pandas pad (forward fill) restated on knot coordinates: the value of the last knot at or before xq; NaN left of
+    the first knot (pandas/_libs/algos.pyx pad_inplace walks the column once and carries the last valid value)."""
+    xv = np.asarray(xv, np.float64); xq = np.asarray(xq, np.float64)
+    j = _interval(xv, xq)
+    out = np.asarray(yv, np.float64)[np.clip(j, 0, xv.size - 1)]
+    return np.where(j >= 0, out, np.nan)
+
+
+def bfill_eval(xv, yv, xq):
+    """pandas backfill restated: the value of the first knot at or after xq; NaN right of the last knot
+    (algos.pyx backfill_inplace = pad_inplace on the reversed column)."""
+    xv = np.asarray(xv, np.float64); xq = np.asarray(xq, np.float64)
+    k = np.searchsorted(xv, xq, side="left")             # first knot >= xq
+    out = np.asarray(yv, np.float64)[np.clip(k, 0, xv.size - 1)]
+    return np.where((k < xv.size) & ~np.isnan(xq), out, np.nan)
 
 
 def bpoly_linear_eval(xv, yv, xq):
@@ -478,6 +514,10 @@ def interp1d(xk, yk, xq, method: int):
         if n > POLY_MAX_KNOTS:
             return np.full(xq.shape, np.nan), ST_ILL_CONDITIONED
         return (barycentric_eval if method == BARYCENTRIC else krogh_eval)(xv, yv, xq), ST_OK
+    if method == PAD:
+        return pad_eval(xv, yv, xq), ST_OK
+    if method == BFILL:
+        return bfill_eval(xv, yv, xq), ST_OK
     if method == LINEAR:
         return lerp_eval(xv, yv, xq, right_hold=True), ST_OK
     if method == SLINEAR:

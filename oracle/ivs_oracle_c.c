@@ -7,6 +7,10 @@
  *   scipy  PPoly coefficient build + Horner (_cubic.py:170-180)             -> hermite()
  *   scipy  PchipInterpolator._find_derivatives/_edge_case (_cubic.py:248-309) -> pchip_slopes()
  *   scipy  Akima1DInterpolator.__init__ (_cubic.py:510-541)                 -> akima_slopes()
+ *   scipy  interp1d kind nearest / zero (_interpolate.py:327-328, 486-501)  -> nearest(), zero()
+ *   scipy  BPoly.from_derivatives on values (_ppoly.pyx evaluate_bpoly1)    -> bpoly_linear()
+ *   scipy  make_interp_spline(k=2) (_bsplines.py; knots at the site midpoints) -> quadratic_coeffs(), quadratic_eval()
+ *   pandas pad / backfill (generic.py NDFrame.interpolate -> pad_or_backfill) -> pad(), bfill()
  * reached by the reference through Series.interpolate (reference src/interpolation/core.py:61).
  * Pinned by tests/test_c_oracle.py against the NumPy oracle and the reference's golden vectors.
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; contraction off keeps 'linear' bit-equal to numpy)
@@ -19,11 +23,20 @@
 #include <omp.h>
 #endif
 
-enum { LINEAR = 0, CUBIC = 1, CUBICSPLINE = 2, SLINEAR = 3, PCHIP = 6, AKIMA = 7 };
+enum { LINEAR = 0, CUBIC = 1, CUBICSPLINE = 2, SLINEAR = 3, NEAREST = 4, ZERO = 5, PCHIP = 6, AKIMA = 7, FROM_DERIVATIVES = 8,
+       QUADRATIC = 9, PAD = 12, BFILL = 13 };
 #define NMAX 1024
 
-static int supported(int m) { return m == LINEAR || m == CUBIC || m == CUBICSPLINE || m == SLINEAR || m == PCHIP || m == AKIMA; }
-static int min_knots(int m) { return m == LINEAR ? 0 : (m == CUBIC ? 4 : (m == AKIMA ? 3 : 2)); }
+static int supported(int m) { return (m >= LINEAR && m <= QUADRATIC) || m == PAD || m == BFILL; }
+static int min_knots(int m) {
+    switch (m) {
+        case LINEAR: case PAD: case BFILL: return 0;
+        case CUBIC: return 4;
+        case NEAREST: case ZERO: return 1;
+        case AKIMA: case QUADRATIC: return 3;
+        default: return 2;
+    }
+}
 
 static int interval(const double* x, int n, double xq) { /* largest j with x[j] <= xq, or -1 */
     int lo = 0, hi = n;
@@ -124,6 +137,76 @@ static double hermite(const double* x, const double* y, const double* s, int n, 
     return ((c0 * u + c1) * u + s[jj]) * u + y[jj];
 }
 
+/* ---- step / fill / Bernstein rules (oracle nearest_eval, zero_eval, pad_eval, bfill_eval, bpoly_linear_eval) */
+static double nearest(const double* x, const double* y, int n, double xq) {
+    if (!(xq >= x[0] && xq <= x[n - 1])) return NAN;
+    int lo = 0, hi = n - 1;            /* searchsorted(x/2 + x_next/2, xq, side='left') */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (x[mid] / 2.0 + x[mid + 1] / 2.0 < xq) lo = mid + 1; else hi = mid; }
+    return y[lo];
+}
+static double zero(const double* x, const double* y, int n, double xq) {
+    int j = interval(x, n, xq);
+    if (j < 0 || !(xq <= x[n - 1])) return NAN;
+    return y[j > n - 1 ? n - 1 : j];
+}
+static double pad(const double* x, const double* y, int n, double xq) {
+    int j = interval(x, n, xq);
+    return j < 0 ? NAN : y[j > n - 1 ? n - 1 : j];
+}
+static double bfill(const double* x, const double* y, int n, double xq) {
+    if (isnan(xq)) return NAN;
+    int lo = 0, hi = n;                /* first knot >= xq */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (x[mid] < xq) lo = mid + 1; else hi = mid; }
+    return lo < n ? y[lo] : NAN;
+}
+static double bpoly_linear(const double* x, const double* y, int n, double xq) {
+    int j = interval(x, n, xq);
+    if (j < 0 || !(xq <= x[n - 1])) return NAN;
+    int jj = j > n - 2 ? n - 2 : j;
+    double s = (xq - x[jj]) / (x[jj + 1] - x[jj]);
+    double a = y[jj] * (1.0 - s), b = y[jj + 1] * s;
+    return a + b;
+}
+
+/* ---- quadratic B-spline (oracle quadratic_coeffs / quadratic_eval) */
+static double quad_knot(const double* x, int n, int j) {      /* t_j, j = 0..n+2 */
+    if (j <= 2) return x[0];
+    if (j >= n) return x[n - 1];
+    return (x[j - 1] + x[j - 2]) / 2.0;
+}
+static void quad_basis(const double* x, int n, int ell, double xv, double* h0, double* h1, double* h2) {
+    double tm1 = quad_knot(x, n, ell - 1), t0 = quad_knot(x, n, ell), t1 = quad_knot(x, n, ell + 1), t2 = quad_knot(x, n, ell + 2);
+    double w = 1.0 / (t1 - t0);
+    double a0 = w * (t1 - xv), a1 = w * (xv - t0);
+    double w1 = a0 / (t1 - tm1);
+    *h0 = 0.0 + w1 * (t1 - xv);
+    *h1 = w1 * (xv - tm1);
+    double w2 = a1 / (t2 - t0);
+    *h1 = *h1 + w2 * (t2 - xv);
+    *h2 = w2 * (xv - t0);
+}
+static void quadratic_coeffs(const double* x, const double* y, int n, double* c) {
+    double cp[NMAX], dp[NMAX];
+    cp[0] = 0.0 / 1.0; dp[0] = y[0] / 1.0;
+    for (int i = 1; i < n; ++i) {
+        double lo = 0.0, di = 1.0, up = 0.0;
+        if (i < n - 1) quad_basis(x, n, i + 1, x[i], &lo, &di, &up);
+        double w = di - lo * cp[i - 1];
+        cp[i] = up / w; dp[i] = (y[i] - lo * dp[i - 1]) / w;
+    }
+    c[n - 1] = dp[n - 1];
+    for (int i = n - 2; i >= 0; --i) c[i] = dp[i] - cp[i] * c[i + 1];
+}
+static double quadratic_eval(const double* x, const double* c, int n, double xq) {
+    if (!(xq >= x[0] && xq <= x[n - 1])) return NAN;
+    int q = 0;                         /* interior knots mid_1..mid_{n-3} that are <= xq (searchsorted side='right') */
+    for (int i = 1; i <= n - 3; ++i) if ((x[i + 1] + x[i]) / 2.0 <= xq) q = i; else break;
+    int ell = q + 2;
+    double h0, h1, h2;
+    quad_basis(x, n, ell, xq, &h0, &h1, &h2);
+    return h0 * c[ell - 2] + h1 * c[ell - 1] + h2 * c[ell];
+}
+
 /* one masked-knot 1-D op: xs/ys stride, NaN = missing; returns status (1 = too few knots) */
 static int interp1d(const double* xk, const double* yk, int ystride, int n, const double* xq, int m, double* out,
                     int ostride, int method) {
@@ -136,6 +219,23 @@ static int interp1d(const double* xk, const double* yk, int ystride, int n, cons
     }
     if (method == LINEAR || method == SLINEAR) {
         for (int q = 0; q < m; ++q) out[(size_t)q * ostride] = lerp(xv, yv, nv, xq[q], method == LINEAR);
+        return 0;
+    }
+    if (method == NEAREST || method == ZERO || method == FROM_DERIVATIVES || method == PAD || method == BFILL) {
+        for (int q = 0; q < m; ++q) {
+            double v;
+            if (method == NEAREST) v = nearest(xv, yv, nv, xq[q]);
+            else if (method == ZERO) v = zero(xv, yv, nv, xq[q]);
+            else if (method == PAD) v = pad(xv, yv, nv, xq[q]);
+            else if (method == BFILL) v = bfill(xv, yv, nv, xq[q]);
+            else v = bpoly_linear(xv, yv, nv, xq[q]);
+            out[(size_t)q * ostride] = v;
+        }
+        return 0;
+    }
+    if (method == QUADRATIC) {
+        quadratic_coeffs(xv, yv, nv, s);
+        for (int q = 0; q < m; ++q) out[(size_t)q * ostride] = quadratic_eval(xv, s, nv, xq[q]);
         return 0;
     }
     if (method == PCHIP) pchip_slopes(xv, yv, nv, s);

@@ -46,20 +46,33 @@ def interpolate_symbol(symbol_data: pd.DataFrame, method: str = "linear",
         if len(timeline) > 100000:                                      # :49-51
             return None
         merged = pd.DataFrame({"date": timeline}).merge(df, on="date", how="left")  # :54-55
-        if method not in O.METHOD_CODES:
+        code = O.method_code(method)
+        if code is None:
             # methods the oracle does not restate: the reference either raises (-> None)
             # or runs another scipy routine that is out of this oracle's scope.
             if method not in VALID_PANDAS_METHODS or method in ("time", "spline", "polynomial"):
                 return None
             raise NotImplementedError(method)
-        code = O.METHOD_CODES[method]
+        fill = code in (O.PAD, O.BFILL)
         m = len(merged)
         pos = np.arange(m, dtype=np.float64)                            # RangeIndex positions (R8)
         for col in NUMERIC_COLS:                                        # :58-61
             if col in merged.columns:
                 dt = merged[col].dtype
-                if dt == object:
+                if dt == object and not fill:
                     continue                                            # Series.interpolate on object dtype: (deprecated) no-op
+                if dt == object:
+                    # the fill methods DO fill object cells (pad_or_backfill), then the block is soft-converted
+                    # (Block._maybe_downcast -> convert): restated on row numbers, which the fill rule moves like values
+                    cells = merged[col].to_numpy()
+                    rows = np.where(pd.isna(cells), np.nan, np.arange(m, dtype=np.float64))
+                    if not np.isnan(rows).all():
+                        val, _ = O.interp1d(pos, rows, pos, code)
+                        filled = np.full(m, np.nan, dtype=object)
+                        ok = ~np.isnan(val)
+                        filled[ok] = cells[val[ok].astype(np.int64)]
+                        merged[col] = pd.Series(filled, dtype=object).infer_objects().to_numpy()
+                    continue
                 y = merged[col].to_numpy(np.float64, na_value=np.nan)
                 if np.isnan(y).all() or not np.isnan(y).any():
                     continue                                            # missing.py:468-472

@@ -227,6 +227,62 @@ for m in ("barycentric", "krogh"):
     add(f"y9_n24_{m}", lattice_frame(np.arange(24) * 9, 124), m, 2)
 
 
+# appended in round 3: the FILL methods.  core.py:61 forwards self.method to Series.interpolate, and pandas 2.x still executes
+# 'pad' / 'ffill' / 'bfill' / 'backfill' there (NDFrame.interpolate -> BlockManager.pad_or_backfill, FutureWarning): forward
+# fill keeps leading NaN and holds the last value, backward fill keeps trailing NaN; object channels ARE filled (and soft-
+# converted to float64), float32 / Float64 keep their dtype
+for m in ("pad", "ffill", "bfill", "backfill"):
+    add(f"z1_{m}", frame(12, 1), m)
+    dfz = frame(14, 5)
+    dfz.loc[4:6, "iv"] = np.nan; dfz.loc[0:1, "underlying_price"] = np.nan; dfz.loc[12:13, "time_to_maturity"] = np.nan
+    dfz.loc[3, "volume"] = np.nan; dfz.loc[0, "strike"] = np.nan; dfz.loc[7, "callput"] = None
+    add(f"z5_nan_{m}", dfz, m)
+for m in ("pad", "bfill"):
+    dfz = frame(14, 41); dfz.loc[6, "date"] = dfz.loc[5, "date"]; dfz.loc[7, "date"] = dfz.loc[5, "date"]
+    dfz.loc[13, "date"] = dfz.loc[12, "date"]; dfz.loc[5, "iv"] = np.nan; dfz.loc[12, "underlying_price"] = np.nan
+    add(f"z4_dup3_{m}", dfz, m)
+    dfz = frame(12, 3); dfz.loc[5, "date"] += pd.Timedelta(seconds=30); dfz.loc[4, "iv"] = np.nan
+    add(f"z3_offgrid_{m}", dfz, m)
+    dfz = frame(12, 51); dfz["iv"] = np.nan
+    add(f"z5_allnan_iv_{m}", dfz, m)
+    dfz = frame(12, 52); dfz.loc[1:, "iv"] = np.nan
+    add(f"z5_oneknot_first_{m}", dfz, m)
+    dfz = frame(12, 52); dfz.loc[:10, "iv"] = np.nan
+    add(f"z5_oneknot_last_{m}", dfz, m)
+    dfz = frame(12, 1); dfz["iv"] = dfz["iv"].astype(object); dfz.loc[3, "iv"] = np.nan
+    add(f"z6_object_iv_{m}", dfz, m)
+    dfz = frame(12, 1); dfz["iv"] = dfz["iv"].astype(np.float32); dfz.loc[3, "iv"] = np.nan
+    add(f"z6_float32_iv_{m}", dfz, m)
+    dfz = frame(12, 1); dfz["iv"] = dfz["iv"].astype("Float64"); dfz.loc[4, "iv"] = pd.NA
+    add(f"z6_Float64_iv_{m}", dfz, m)
+    dfz = frame(12, 1); dfz["time_to_maturity"] = np.arange(12)
+    add(f"z6_int_ttm_{m}", dfz, m)
+    add(f"z8_64to256_{m}", lattice_frame(p64, 80), m, 2)
+    for n in (2, 3):
+        add(f"z9_few{n}_{m}", lattice_frame(np.arange(n) * 20, 99 + n), m, 2)
+    dfz = frame(24, 700)
+    for i in (5, 11, 12, 20):
+        dfz.loc[i, "date"] = dfz.loc[i - 1, "date"]
+    dfz.loc[11, "iv"] = np.nan
+    add(f"z4_dup_gt16_{m}", dfz.sample(frac=1.0, random_state=71).reset_index(drop=True), m, 2)
+add("z7_upper_PAD", frame(12, 1), "PAD")
+add("z7_upper_BFILL", frame(12, 1), "BFILL"); add("z7_mixed_Ffill", frame(12, 1), "Ffill"); add("z7_upper_LINEAR", frame(12, 1), "LINEAR")
+rz = np.random.default_rng(20261005)
+for k in range(24):
+    n = int(rz.integers(10, 60))
+    dfz = frame(n, 3000 + k, freq=rz.choice(["1h", "30min", "7min", "2h"]))
+    for c in ("iv", "underlying_price", "time_to_maturity", "volume", "strike"):
+        msk = rz.random(n) < rz.choice([0.0, 0.1, 0.4])
+        dfz.loc[msk, c] = np.nan
+    if rz.random() < 0.3:
+        i = int(rz.integers(1, n)); dfz.loc[i, "date"] = dfz.loc[i - 1, "date"]
+    if rz.random() < 0.3:
+        i = int(rz.integers(1, n - 1)); dfz.loc[i, "date"] += pd.Timedelta(seconds=int(rz.integers(1, 59)))
+    if rz.random() < 0.5:
+        dfz = dfz.sample(frac=1.0, random_state=k).reset_index(drop=True)
+    add(f"zfuzz{k:02d}", dfz, str(rz.choice(["pad", "ffill", "bfill", "backfill"])), int(rz.choice([2, 10])))
+
+
 def enc(col: pd.Series):
     """Encode a column without pickling: returns dict of arrays + dtype tag."""
     dt = str(col.dtype)
@@ -286,7 +342,7 @@ def main():
         return r.loc[xq].to_numpy()
 
     ALL_METHODS = ("linear", "cubic", "cubicspline", "slinear", "nearest", "zero", "pchip", "akima", "from_derivatives",
-                   "quadratic")
+                   "quadratic", "pad", "bfill")      # the last two since round 3 (deterministic: earlier vectors unchanged)
     r1 = np.random.default_rng(11)
     real = {}
     k = 0

@@ -54,7 +54,8 @@ class SymbolCases:
         return df
 
 
-EXACT_METHODS = ("linear", "index", "values", "nearest", "zero", "from_derivatives", "piecewise_polynomial")
+EXACT_METHODS = ("linear", "index", "values", "nearest", "zero", "from_derivatives", "piecewise_polynomial",
+                 "pad", "ffill", "bfill", "backfill", "PAD", "BFILL", "Ffill")
 POLY_METHODS = ("barycentric", "krogh")
 
 

@@ -18,7 +18,8 @@ except FileNotFoundError:
     pytest.skip("libivs_oracle.so not built (make -C oracle)", allow_module_level=True)
 
 
-@pytest.mark.parametrize("method", [O.LINEAR, O.CUBIC, O.CUBICSPLINE, O.SLINEAR, O.PCHIP, O.AKIMA])
+@pytest.mark.parametrize("method", [O.LINEAR, O.CUBIC, O.CUBICSPLINE, O.SLINEAR, O.PCHIP, O.AKIMA, O.NEAREST, O.ZERO,
+                                    O.FROM_DERIVATIVES, O.QUADRATIC, O.PAD, O.BFILL])
 def test_equals_numpy_oracle_dense_and_masked(method):
     Kq, Tq = synth.query_grids(64, 16)
     for nan_frac in (0.0, 0.2):
@@ -38,12 +39,13 @@ def test_ragged_and_golden_surfaces():
     g = np.load(os.path.join(GOLDEN, "surfaces.npz"))
     for k in range(int(g["n_cases"])):
         K, T, s, Kq, Tq = [g[f"s{k}/{n}"] for n in ("K", "T", "sigma", "Kq", "Tq")]
-        for m, code in (("linear", O.LINEAR), ("cubic", O.CUBIC)):
+        for m, code in (("linear", O.LINEAR), ("cubic", O.CUBIC), ("quadratic", O.QUADRATIC), ("nearest", O.NEAREST),
+                        ("zero", O.ZERO), ("from_derivatives", O.FROM_DERIVATIVES), ("pad", O.PAD), ("bfill", O.BFILL)):
             if bool(g[f"s{k}/{m}_raised"]):
                 continue
             got, _ = RUN.surface_batch(K[None], T, s[None], Kq, Tq, code)
             exp = g[f"s{k}/{m}"]
-            if m == "linear":
+            if m not in ("cubic", "quadratic"):
                 assert np.array_equal(got[0], exp, equal_nan=True)
             else:
                 assert np.allclose(got[0], exp, rtol=1e-12, atol=1e-13, equal_nan=True)

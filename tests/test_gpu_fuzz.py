@@ -110,4 +110,13 @@ def test_random_case_matches_oracle(seed):
     if c["method"] in EXACT:
         assert np.array_equal(got, ref, equal_nan=True), (tagd, np.nanmax(np.abs(got - ref)))
     else:
-        assert np.allclose(got, ref, rtol=1e-10, atol=1e-11 * c["scale"], equal_nan=True), (tagd, np.nanmax(np.abs(got - ref)))
+        # random shapes, NaN patterns, units and queries up to 10 % / 30 % outside the hull (cubicspline / pchip extrapolate):
+        # 1e-12 relative (rounds 1-2: 1e-10; measured on the 120 default seeds: see profiles/r03/fuzz_errors.txt)
+        path = os.environ.get("IVS_ERRLOG")
+        if path:
+            with np.errstate(all="ignore"):
+                dd = np.abs(got - ref); okk = np.isfinite(dd)
+                rel = float(np.max(dd[okk] / (0.1 * c["scale"] + np.abs(ref[okk])))) if okk.any() else 0.0
+            with open(path, "a") as f:
+                f.write(f"{rel:.3e} fuzz {tagd}\n")
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-13 * c["scale"], equal_nan=True), (tagd, np.nanmax(np.abs(got - ref)))

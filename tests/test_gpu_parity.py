@@ -1,7 +1,9 @@
 """GPU: the HIP path, called through the C ABI, against the oracle and the committed golden
 vectors.  Tolerances: 'linear' is BIT-EXACT (np.interp arithmetic reproduced); the spline methods
-are compared at rtol 1e-11 / atol 1e-12 against the oracle (measured ~1e-15) and at
-rtol 1e-12 / atol 1e-13 against the reference's golden outputs."""
+are compared at rtol 1e-13 / atol 1e-14 against the oracle on the well-conditioned synthetic configs (measured <= 2e-15;
+rounds 1-2 allowed 1e-11 / 1e-12, four orders looser than what is measured) and at rtol 1e-12 / atol 1e-13 against the
+reference's golden outputs; the ill-conditioned grids keep their own stated bounds (test_ill_conditioned_*).
+IVS_ERRLOG=<file> appends the measured error of every comparison (calibration of the numbers above)."""
 import os
 import sys
 
@@ -17,11 +19,11 @@ pytestmark = pytest.mark.gpu
 
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
            "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES,
-           "quadratic": O.QUADRATIC}
+           "quadratic": O.QUADRATIC, "pad": O.PAD, "bfill": O.BFILL}
 DENSE_METHODS = ["linear", "cubic", "cubicspline", "slinear", "pchip", "akima"]     # methods with dense and variable-shape kernels
 DENSE64_METHODS = DENSE_METHODS
-EXACT = ("linear", "nearest", "zero", "from_derivatives")               # bit-exact against the oracle / pandas
-RTOL, ATOL = 1e-11, 1e-12
+EXACT = ("linear", "nearest", "zero", "from_derivatives", "pad", "bfill")               # bit-exact against the oracle / pandas
+RTOL, ATOL = 1e-13, 1e-14
 CASES = SymbolCases()
 
 
@@ -35,8 +37,19 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def _errlog(what, got, ref):
+    path = os.environ.get("IVS_ERRLOG")
+    if path:
+        with np.errstate(all="ignore"):
+            d = np.abs(got - ref); ok = np.isfinite(d)
+            rel = float(np.max(d[ok] / (ATOL / RTOL + np.abs(ref[ok])))) if ok.any() else 0.0
+        with open(path, "a") as f:
+            f.write(f"{rel:.3e} {float(np.max(d[ok])) if ok.any() else 0.0:.3e} {what}\n")
+
+
 def close(got, ref, method, what=""):
     assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern"
+    _errlog(what, got, ref)
     if method in EXACT:
         assert np.array_equal(got, ref, equal_nan=True), f"{what}: {method} not bit-exact, max diff {np.nanmax(np.abs(got - ref))}"
     else:
@@ -128,13 +141,13 @@ def _run(d, Kq, Tq, method, **kw):
 def test_config2_10k_surfaces_vs_oracle(method, force_generic):
     """BASELINE config 2: 10k synthetic snapshots, 64x16 -> 64x16, every surface compared."""
     from iv_interpolation_amd import synth
-    in_c = method in ("linear", "cubic", "cubicspline", "slinear", "pchip", "akima")
-    # the three methods only the (slow, per-surface) NumPy oracle restates are checked on the first 2000 surfaces
-    d = synth.numpy_batch(10000 if in_c else (400 if method == "quadratic" else 2000), 64, 16, seed=synth.BASE_SEED)
+    # all 10 000 surfaces for every method: the C oracle restates all of them (round 3; rounds 1-2 compared 400 / 2000
+    # surfaces for the four methods only the per-surface NumPy oracle restated)
+    d = synth.numpy_batch(10000, 64, 16, seed=synth.BASE_SEED)
     Kq, Tq = synth.query_grids(64, 16)
     got, st, kern = _run(d, Kq, Tq, method, force_generic=force_generic)
     ref = None
-    if method in ("pchip", "akima"):          # C oracle = NumPy oracle bit for bit (tests/test_c_oracle.py), 50x faster here
+    if method not in ("linear", "cubic", "cubicspline", "slinear"):      # C oracle = NumPy oracle bit for bit (tests/test_c_oracle.py)
         try:
             import c_oracle
             ref, rst = c_oracle.load().surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, METHODS[method])
@@ -801,3 +814,86 @@ def test_overlapping_calls_on_two_streams_with_their_own_workspaces():
             engine.surface_batch(d2["K"], d2["T"], d2["sigma"], Kq, Tq, "pchip", out=o2, status=st2, workspace=w2, **kw2)
         torch.cuda.synchronize()
         assert torch.equal(o1, ref1) and torch.equal(o2, ref2), rep
+
+
+def test_ragged_offsets_are_guarded_on_the_device():
+    """include/ivs.h (ABI 3): ragged calls pass the total strike count; a surface whose span is negative, exceeds nK_max or
+    leaves K gets ST_BAD_SHAPE and is skipped by every kernel family -- no host-side validation (and no D2H read) is needed.
+    Every other surface of the batch still equals the oracle; validate=True raises a readable error instead."""
+    import torch
+    from iv_interpolation_amd import _lib, engine, synth
+    d = synth.numpy_ragged_batch(300, 16, 8, 128, seed=synth.BASE_SEED + 90)
+    Kq, Tq = synth.query_grids(64, 16)
+    total = int(d["k_off"][-1])
+    ref, rst = O.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, O.CUBIC, k_off=d["k_off"])
+    for method, kw in (("cubic", {}), ("cubic", dict(one_pass=True)), ("cubic", dict(force_generic=True)), ("pad", {})):
+        bad = d["k_off"].copy()
+        bad[-1] = total + 40                       # last surface leaves K / sigma (its span alone, <= 128, looks fine)
+        span_last = bad[-1] - bad[-2]
+        bad[100] = bad[99] - 3                     # negative span at 99, and a span over nK_max may follow at 100
+        out = torch.full((300, 16, 64), -7.0, dtype=torch.float64, device="cuda")
+        _, st = engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method, k_off=dev(bad),
+                                     nK_max=d["nK_max"], n_maturities=16, out=out, **kw)
+        torch.cuda.synchronize()
+        st = st.cpu().numpy(); got = out.cpu().numpy()
+        assert st[99] == _lib.ST_BAD_SHAPE and (got[99] == -7.0).all(), (method, kw, st[99])
+        if span_last <= d["nK_max"]:
+            assert st[299] == _lib.ST_BAD_SHAPE and (got[299] == -7.0).all(), (method, kw, st[299])
+        good = np.ones(300, bool); good[[99, 100, 299]] = False
+        if method == "cubic":
+            assert np.array_equal(st[good], rst[good])
+            close(got[good], ref[good], "cubic", f"guarded ragged {kw}")
+        with pytest.raises(ValueError):
+            engine.surface_batch(dev(d["K"]), dev(d["T"]), dev(d["sigma"]), dev(Kq), dev(Tq), method, k_off=dev(bad),
+                                 nK_max=d["nK_max"], n_maturities=16, validate=True, **kw)
+
+
+def test_explicit_stream_without_a_workspace_survives_reallocation():
+    """engine.surface_batch(stream=s) without a caller workspace allocates its scratch on torch's CURRENT stream and launches
+    on `s`: the block must not be handed to the next allocation while the persistent kernels still use it (record_stream).
+    Allocate and scribble on the default stream right after the call; the result must equal the synchronous one."""
+    import torch
+    from iv_interpolation_amd import engine, synth
+    Kq, Tq = synth.query_grids(64, 16)
+    Kq, Tq = dev(Kq), dev(Tq)
+    B = 200000
+    d = synth.torch_batch(B, 64, 16, seed=synth.BASE_SEED + 91)
+    r = synth.torch_ragged_batch(B // 4, 16, 8, 128, seed=synth.BASE_SEED + 92)
+    kwr = dict(k_off=r["k_off"], nK_max=128, n_maturities=16)
+    ref1, _ = engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic")
+    ref2, _ = engine.surface_batch(r["K"], r["T"], r["sigma"], Kq, Tq, "cubic", **kwr)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    for rep in range(3):
+        torch.cuda.empty_cache()
+        s.wait_stream(torch.cuda.current_stream())
+        o1, _ = engine.surface_batch(d["K"], d["T"], d["sigma"], Kq, Tq, "cubic", stream=s)
+        junk = [torch.full((n,), 255, dtype=torch.uint8, device="cuda") for n in (4096, 1 << 16, 1 << 20, 6 << 20)]
+        o2, _ = engine.surface_batch(r["K"], r["T"], r["sigma"], Kq, Tq, "cubic", stream=s, **kwr)
+        junk += [torch.full((n,), 255, dtype=torch.uint8, device="cuda") for n in (4096, 1 << 16, 1 << 20, 6 << 20)]
+        s.synchronize()
+        assert torch.equal(o1, ref1) and torch.equal(o2, ref2), rep
+        del junk
+
+
+@pytest.mark.parametrize("method", ["pad", "bfill"])
+def test_fill_methods_1d_batch_vs_oracle(method):
+    """'pad' / 'bfill' on the 1-D kernels (the reference's own shape): hourly knots with NaN runs at either end and inside,
+    duplicate-free integer lattice; bit-exact against the oracle (no arithmetic: values are copied)."""
+    import torch
+    from iv_interpolation_amd import engine
+    r = np.random.default_rng(77)
+    S, C = 300, 3
+    n = r.integers(1, 90, S)
+    koff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    xk = np.concatenate([np.sort(r.choice(np.arange(0, 60 * k + 1), k, replace=False)).astype(np.float64) for k in n])
+    yk = r.normal(0.6, 0.1, (C, int(koff[-1])))
+    yk[r.random(yk.shape) < 0.3] = np.nan
+    yk[0, koff[5]:koff[6]] = np.nan                  # a channel without any knot
+    m = np.array([int(xk[koff[i + 1] - 1]) + 1 + int(r.integers(0, 30)) for i in range(S)])
+    qoff = np.concatenate([[0], np.cumsum(m)]).astype(np.int64)
+    out, st = engine.interp1d_batch(dev(xk), dev(yk), dev(koff), dev(qoff), int(qoff[-1]), method)
+    torch.cuda.synchronize()
+    ref, rst = O.interp1d_batch(xk, yk, koff, None, qoff, METHODS[method])
+    assert np.array_equal(st.cpu().numpy(), rst)
+    assert np.array_equal(out.cpu().numpy(), ref, equal_nan=True)

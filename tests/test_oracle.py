@@ -14,8 +14,8 @@ from golden_io import GOLDEN, SymbolCases, assert_symbol_frame, method_tolerance
 CASES = SymbolCases()
 METHODS = {"linear": O.LINEAR, "cubic": O.CUBIC, "cubicspline": O.CUBICSPLINE, "slinear": O.SLINEAR,
            "nearest": O.NEAREST, "zero": O.ZERO, "pchip": O.PCHIP, "akima": O.AKIMA, "from_derivatives": O.FROM_DERIVATIVES,
-           "quadratic": O.QUADRATIC}
-EXACT = ("linear", "nearest", "zero", "from_derivatives")
+           "quadratic": O.QUADRATIC, "pad": O.PAD, "bfill": O.BFILL}
+EXACT = ("linear", "nearest", "zero", "from_derivatives", "pad", "bfill")
 # fp64 tolerance for the spline methods on the golden shapes (measured <= 1e-15)
 RTOL, ATOL = 1e-12, 1e-13
 
