@@ -740,9 +740,31 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
     int tq = 0;
     double* rp = outb + q0;                                    // row tq of the output block: uniform running pointer
     cdptr wp = cW;                                             // SM: weights of row tq
+#ifdef IVS_PUT_PAIR
+    // A/B variant (verdict r02 item 8): 16 bytes per lane -- rows are stored in PAIRS, lane pair (2i, 2i+1)
+    // swaps one value through a quad_perm DPP move, the even lane writes strikes (2i, 2i+1) of the even row, the odd lane
+    // those of the odd row: half the store instructions, 1 KB per instruction.  Needs mK even and a 16-byte aligned block.
+    const bool pair_ok = !RANGED && (mK & 1) == 0 && ((reinterpret_cast<uintptr_t>(outb + q0) & 15) == 0);      // wave-uniform
+    const int pair_off = (lane & 1) ? lane - 1 : lane - mK;
+    double pend = 0.0;
+#endif
     auto put = [&](int row, double v) {                        // row == tq at every call site
         (void)row;
         if (ABL == 4 && (row & 7) != 0) { asm volatile("" :: "v"(v)); return; }
+#ifdef IVS_PUT_PAIR
+        if (pair_ok) {
+            if (!(tq & 1)) {
+                pend = v;
+                if (tq == mT - 1 && act) rp[lane] = v;         // an odd row count leaves the last row unpaired
+            } else {
+                const double send = (lane & 1) ? pend : v;
+                const double recv = dpp_f64<0xB1>(send, send);       // quad_perm [1, 0, 3, 2]
+                double2 o; o.x = (lane & 1) ? recv : pend; o.y = (lane & 1) ? v : recv;
+                if (act) *reinterpret_cast<double2*>(rp + pair_off) = o;
+            }
+            return;
+        }
+#endif
         if (act) rp[lane] = v;
     };
     auto adv = [&]() { ++tq; rp += mK; wp += 4; };

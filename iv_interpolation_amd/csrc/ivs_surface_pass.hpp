@@ -46,6 +46,16 @@
 #ifndef IVS_PASS_PFP4
 #define IVS_PASS_PFP4 2
 #endif
+#ifndef IVS_PASS_WIDE
+// A/B variant, REJECTED (round 3, profiles/r03/ab_cfg5_wide_staging_and_ablations.txt): run-time-shape kernels staging their
+// quotes with 16 B per lane (a lane takes TWO neighbouring strikes of a row; 64 strikes: one load covers two rows, 128
+// strikes: one row) instead of one row of 8-byte loads with the lanes beyond n idle.  Half the VMEM and LDS-store
+// instructions per pass, bit-identical results -- and 2-5 % SLOWER in every size class (65..128: 186.7 -> 183.8 M surfaces/s,
+// 8..64: 311.6 -> 298.3): these kernels are bound by their arithmetic phases (the ablations in the same file: K-phase +
+// sweeps cost 25-37 % of the call, the no-math skeleton streams at 5.5-5.7 TB/s), not by load / store instruction issue,
+// and the pair addressing costs 12-16 B of scratch at 168 VGPRs.
+#define IVS_PASS_WIDE 0
+#endif
 namespace ivs {
 
 template <int NKB, int SL = 8>
@@ -541,6 +551,22 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
             }
         } else {
             const double* sb = p.k_off ? p.sigma + (int64_t)nT * ko : p.sigma + b * (int64_t)nT * p.nK;
+#if IVS_PASS_WIDE
+            // lane = (row of a row pair, strike pair): rows are nn doubles apart, so a pair is 8-byte aligned only (global
+            // loads take that); the last strike of an odd row is fetched alone -- its pair would reach into the next row,
+            // and behind the last row of the batch past the end of the caller's array
+            typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
+            constexpr int LPR = 32 * NKB;                        // lanes per row
+#pragma unroll
+            for (int c = 0; c < PPL / 2; ++c) {
+                const int t = ps * RP + (NKB == 1 ? 2 * c + (lane >> 5) : c), k = 2 * (lane & (LPR - 1));
+                const double* src = sb + (int64_t)t * nn + k;
+                double2 v = double2{0.0, 0.0};                   // rows beyond nT, strikes beyond n: zeros
+                if (t < nT && k + 1 < nn) { const v2d_a8 w = *reinterpret_cast<const v2d_a8*>(src); v.x = w.x; v.y = w.y; }
+                else if (t < nT && k < nn) v.x = *src;
+                pre[slot * PPL + 2 * c] = v.x; pre[slot * PPL + 2 * c + 1] = v.y;
+            }
+#else
 #pragma unroll
             for (int r = 0; r < RP; ++r)
 #pragma unroll
@@ -548,6 +574,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                     const int t = ps * RP + r, k = blk * 64 + lane;
                     pre[(slot * RP + r) * NKB + blk] = (t < nT && k < nn) ? sb[(int64_t)t * nn + k] : 0.0;      // rows beyond nT: zeros
                 }
+#endif
         }
         if (ps == 0) {
 #pragma unroll
@@ -611,6 +638,15 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
 #pragma unroll
                 for (int c = 0; c < RP; ++c) acc = __builtin_fma(pre[slot * RP + c], 0.0, acc);
             } else {
+#if IVS_PASS_WIDE
+#pragma unroll
+                for (int c = 0; c < PPL / 2; ++c) {
+                    const int tl = NKB == 1 ? 2 * c + (lane >> 5) : c, k = 2 * (lane & (32 * NKB - 1));
+                    double2 v; v.x = pre[slot * PPL + 2 * c]; v.y = pre[slot * PPL + 2 * c + 1];
+                    *reinterpret_cast<double2*>(&Yp[tl * RS + y_swz<NKB>(k)]) = v;       // the slot swizzle keeps a pair together
+                    acc = __builtin_fma(v.x, 0.0, acc); acc = __builtin_fma(v.y, 0.0, acc);
+                }
+#else
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
 #pragma unroll
@@ -619,6 +655,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
                         Yp[r * RS + y_swz<NKB>(blk * 64 + lane)] = v;
                         acc = __builtin_fma(v, 0.0, acc);
                     }
+#endif
             }
             if (ps == 0) {
                 bool same = tables_ok && n == n_prev;
@@ -849,9 +886,6 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         IVS_PASS_LAUNCH(1, false, FSL, (FSL == 4 ? 16 : 12), none)
         *name = names[0][mi];
     } else {
-#ifdef IVS_DIAG_MINIMAL
-        return 0;
-#else
         VarItem* lists = nullptr;
         int32_t* counts = nullptr;
         if (p.k_off) {      // classify once into one work list per size class (workspace: counters, then B items per class)
@@ -868,7 +902,6 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         if (need1) IVS_PASS_LAUNCH(1, true, 8, 12, wl1)
         if (need2) IVS_PASS_LAUNCH(2, true, 8, IVS_PASS_CAP2, wl2)
         *name = names[1][mi];
-#endif
     }
 #undef IVS_PASS_LAUNCH
     if (hipGetLastError() != hipSuccess) return -1;
