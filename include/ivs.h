@@ -159,6 +159,45 @@ int ivs_frame_rows(const int64_t* q_off, int64_t n_series, int64_t total_queries
                    const int32_t* status, const uint8_t* needs, int64_t* date_ns, uint8_t* keep, void* stream);
 
 /*
+ * The whole long output frame in ONE pass over its rows (core.py:54-74 for S symbols at once; ABI 3): what the five calls
+ * above do together -- ivs_interp1d[_greeks]_batch_f64 on the integer lattice, ivs_ffill_index_batch, ivs_gather_rows_f64 /
+ * _i32 and ivs_frame_rows -- without the forward-fill index ever reaching memory: a block owns 1024 consecutive output rows,
+ * stages the source rows of its symbols in LDS, a thread walks four consecutive rows (one interval search per thread, not per
+ * row and channel) and every column leaves as 16-byte stores.  Same results as the separate calls, bit for bit.
+ *
+ *   src_pos [total_src], src_off [S+1], q_off [S+1]   as in ivs_ffill_index_batch; src_off is also the CSR of the knots
+ *   yk [C][yk_stride], chan_out [C][chan_stride], status [S*C], method          as in ivs_interp1d_batch_f64 (xq = the lattice)
+ *   valid [n_valid][valid_stride]                   validity rows (1 = source cell non-null), n_valid <= 16 on the fast path
+ *   fsrc [n_f][fsrc_stride] f64 / csrc [n_c][csrc_stride] i32   source columns; f_rows [n_f] / c_rows [n_c] (device) = the
+ *                                                   validity row each column forward-fills by; f_out [n_f][f_stride],
+ *                                                   c_out [n_c][c_stride] (missing: NaN / -1)
+ *   idx_rows [n_idx] (device), idx_out [n_idx][idx_stride]      raw gather index (flat source row or -1) of these validity
+ *                                                   rows, for columns the host gathers itself; n_idx may be 0
+ *   first_ns [S], needs [S*C], sym_col, date_ns [total_queries], keep [total_queries]   as in ivs_frame_rows; sym_col = the
+ *                                                   code column that holds the symbol (its -1 drops the row) or -1;
+ *                                                   date_ns == NULL skips both
+ *   g_strike / g_rate / g_put, strike_src, rate_src, put_src, ch_*, greeks [5][greeks_stride]   as in
+ *                                                   ivs_interp1d_greeks_batch_f64 with validity rows in place of fill_idx
+ *                                                   rows; greeks == NULL: no epilogue
+ *   workspace   ivs_frame_workspace_bytes(total_src, S, C) bytes
+ */
+typedef struct ivs_frame_args {
+    const int64_t* src_pos; const int64_t* src_off; const int64_t* q_off;
+    int64_t n_series, total_src, total_queries;
+    const double* yk; int64_t yk_stride; int32_t n_channels; int32_t method;
+    double* chan_out; int64_t chan_stride; int32_t* status;
+    const uint8_t* valid; int64_t valid_stride; int32_t n_valid;
+    const double* fsrc; int64_t fsrc_stride; const int32_t* f_rows; int32_t n_f; double* f_out; int64_t f_stride;
+    const int32_t* csrc; int64_t csrc_stride; const int32_t* c_rows; int32_t n_c; int32_t* c_out; int64_t c_stride;
+    const int32_t* idx_rows; int32_t n_idx; int32_t* idx_out; int64_t idx_stride;
+    const int64_t* first_ns; const uint8_t* needs; int32_t sym_col; int64_t* date_ns; uint8_t* keep;
+    int32_t g_strike, g_rate, g_put; const double* strike_src; const double* rate_src; const uint8_t* put_src;
+    int32_t ch_iv, ch_underlying, ch_ttm; double* greeks; int64_t greeks_stride;
+} ivs_frame_args;
+size_t ivs_frame_workspace_bytes(int64_t total_src, int64_t n_series, int32_t n_channels);
+int ivs_frame_columns_f64(const ivs_frame_args* args /* host */, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Batch of (strike x maturity) surfaces: strike pass then maturity pass, each pass the
  * 1-D operator above (this repository's documented composition).
  *

@@ -59,6 +59,23 @@ class EngineError(RuntimeError):
 _p = C.c_void_p
 _i64, _i32, _sz = C.c_int64, C.c_int32, C.c_size_t
 
+
+
+class FrameArgs(C.Structure):
+    """ivs_frame_args of include/ivs.h (field for field)."""
+    _fields_ = [("src_pos", _p), ("src_off", _p), ("q_off", _p),
+                ("n_series", _i64), ("total_src", _i64), ("total_queries", _i64),
+                ("yk", _p), ("yk_stride", _i64), ("n_channels", _i32), ("method", _i32),
+                ("chan_out", _p), ("chan_stride", _i64), ("status", _p),
+                ("valid", _p), ("valid_stride", _i64), ("n_valid", _i32),
+                ("fsrc", _p), ("fsrc_stride", _i64), ("f_rows", _p), ("n_f", _i32), ("f_out", _p), ("f_stride", _i64),
+                ("csrc", _p), ("csrc_stride", _i64), ("c_rows", _p), ("n_c", _i32), ("c_out", _p), ("c_stride", _i64),
+                ("idx_rows", _p), ("n_idx", _i32), ("idx_out", _p), ("idx_stride", _i64),
+                ("first_ns", _p), ("needs", _p), ("sym_col", _i32), ("date_ns", _p), ("keep", _p),
+                ("g_strike", _i32), ("g_rate", _i32), ("g_put", _i32), ("strike_src", _p), ("rate_src", _p), ("put_src", _p),
+                ("ch_iv", _i32), ("ch_underlying", _i32), ("ch_ttm", _i32), ("greeks", _p), ("greeks_stride", _i64)]
+
+
 # every symbol include/ivs.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "ivs_version": (C.c_int, []),
@@ -75,6 +92,8 @@ SIGNATURES = {
     "ivs_gather_rows_f64": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "ivs_gather_rows_i32": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "ivs_frame_rows": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "ivs_frame_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "ivs_frame_columns_f64": (C.c_int, [C.POINTER(FrameArgs), _p, _sz, _p]),
     "ivs_bs_greeks_f64": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "ivs_candle_aggregate_f64": (C.c_int, [_p] * 7 + [_i64, _i64, _i64] + [_p] * 8),
     "ivs_bridge_workspace_bytes": (C.c_size_t, [_i64]),

@@ -113,6 +113,8 @@ class HipBackend:
         return out.cpu().numpy(), st.cpu().numpy(), gr.cpu().numpy()
 
 
+    fused = True       # one pass over the output rows (ivs_frame_columns_f64); False: the five separate calls of rounds 1-2 (A/B, tests)
+
     def frame_columns(self, pos, chan, src_off, q_off, total_q, code, valid, fsrc, f_rows, csrc, c_rows, host_rows, greek,
                       rows_info=None):
         """Everything interpolate_frame needs from the device in ONE round trip: the three merged channel columns, the
@@ -124,20 +126,46 @@ class HipBackend:
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         ko, qo = d(src_off), d(q_off)
         pos_d = d(pos)
-        fidx = engine.ffill_index_batch(pos_d, ko, d(valid), qo, int(total_q)) if valid.shape[0] else None
-        yk = d(np.stack(chan)); xk = pos_d.to(torch.float64)
-        gr = None
-        if greek is not None:
-            gvalid, ksrc, rsrc, psrc = greek
-            gidx = engine.ffill_index_batch(pos_d, ko, d(gvalid), qo, int(total_q))
-            out, st, gr = engine.interp1d_greeks_batch(xk, yk, ko, qo, int(total_q), code, (0, 1, 2), gidx, (0, 1, 2),
-                                                       d(ksrc), d(rsrc), d(psrc))
+        total_q = int(total_q)
+        yk = d(np.stack(chan))
+        fidx = gr = dts = kp = None
+        if self.fused:
+            vall, g = valid, None
+            if greek is not None:
+                gvalid, ksrc, rsrc, psrc = greek
+                nv = valid.shape[0]
+                vall = np.concatenate([valid, gvalid]) if nv else gvalid
+                g = ((nv, nv + 1, nv + 2), d(ksrc), d(rsrc), d(psrc))
+            i32 = lambda v: d(np.asarray(v, np.int32)) if len(v) else None  # noqa: E731
+            first_ns = needs = None; sym_col = -1
+            if rows_info is not None:
+                fns, nds, sym_row = rows_info
+                first_ns, needs = d(fns), d(np.ascontiguousarray(nds).astype(np.uint8))
+                sym_col = -1 if sym_row is None else int(sym_row)
+            r = engine.frame_columns(pos_d, ko, qo, total_q, yk, code, d(vall) if vall.shape[0] else None,
+                                     d(fsrc) if len(f_rows) else None, i32(f_rows), d(csrc) if len(c_rows) else None, i32(c_rows),
+                                     i32(host_rows), first_ns, needs, sym_col, g)
+            out, st, F, Cc, gr, dts, kp = r["chan"], r["status"], r["F"], r["C"], r["greeks"], r["date_ns"], r["keep"]
+            idx_rows = r["idx"]
         else:
-            out, st = engine.interp1d_batch(xk, yk, ko, qo, int(total_q), code)
-        F = engine.gather_rows(d(fsrc), fidx, d(np.asarray(f_rows, np.int32))) if len(f_rows) else None
-        Cc = engine.gather_rows(d(csrc), fidx, d(np.asarray(c_rows, np.int32))) if len(c_rows) else None
+            fidx = engine.ffill_index_batch(pos_d, ko, d(valid), qo, total_q) if valid.shape[0] else None
+            xk = pos_d.to(torch.float64)
+            if greek is not None:
+                gvalid, ksrc, rsrc, psrc = greek
+                gidx = engine.ffill_index_batch(pos_d, ko, d(gvalid), qo, total_q)
+                out, st, gr = engine.interp1d_greeks_batch(xk, yk, ko, qo, total_q, code, (0, 1, 2), gidx, (0, 1, 2),
+                                                           d(ksrc), d(rsrc), d(psrc))
+            else:
+                out, st = engine.interp1d_batch(xk, yk, ko, qo, total_q, code)
+            F = engine.gather_rows(d(fsrc), fidx, d(np.asarray(f_rows, np.int32))) if len(f_rows) else None
+            Cc = engine.gather_rows(d(csrc), fidx, d(np.asarray(c_rows, np.int32))) if len(c_rows) else None
+            if rows_info is not None:                              # timestamps + keep flags formed on the device
+                first_ns, needs, sym_row = rows_info
+                sym_code = Cc[sym_row] if (Cc is not None and sym_row is not None) else None
+                dts, kp = engine.frame_rows(qo, d(first_ns), out, sym_code, st, d(needs.astype(np.uint8)))
+            idx_rows = None if not len(host_rows) else torch.stack([fidx[r] for r in host_rows])
         n64 = 3 + (len(f_rows) if F is not None else 0) + (5 if gr is not None else 0)
-        h64 = torch.empty((n64, int(total_q)), dtype=torch.float64, pin_memory=True)
+        h64 = torch.empty((n64, total_q), dtype=torch.float64, pin_memory=True)
         h64[:3].copy_(out, non_blocking=True)
         k = 3
         if F is not None:
@@ -145,19 +173,16 @@ class HipBackend:
         if gr is not None:
             h64[k:k + 5].copy_(gr, non_blocking=True)
         dates_h = keep_h = None
-        if rows_info is not None:                                  # timestamps + keep flags formed on the device
-            first_ns, needs, sym_row = rows_info
-            sym_code = Cc[sym_row] if (Cc is not None and sym_row is not None) else None
-            dts, kp = engine.frame_rows(qo, d(first_ns), out, sym_code, st, d(needs.astype(np.uint8)))
-            dates_h = torch.empty(int(total_q), dtype=torch.int64, pin_memory=True); dates_h.copy_(dts, non_blocking=True)
-            keep_h = torch.empty(int(total_q), dtype=torch.uint8, pin_memory=True); keep_h.copy_(kp, non_blocking=True)
+        if dts is not None:
+            dates_h = torch.empty(total_q, dtype=torch.int64, pin_memory=True); dates_h.copy_(dts, non_blocking=True)
+            keep_h = torch.empty(total_q, dtype=torch.uint8, pin_memory=True); keep_h.copy_(kp, non_blocking=True)
         n32 = (len(c_rows) if Cc is not None else 0) + len(host_rows)
-        h32 = torch.empty((max(n32, 1), int(total_q)), dtype=torch.int32, pin_memory=True)
+        h32 = torch.empty((max(n32, 1), total_q), dtype=torch.int32, pin_memory=True)
         j = 0
         if Cc is not None:
             h32[:len(c_rows)].copy_(Cc, non_blocking=True); j = len(c_rows)
-        for r in host_rows:
-            h32[j].copy_(fidx[r], non_blocking=True); j += 1
+        if idx_rows is not None:
+            h32[j:j + len(host_rows)].copy_(idx_rows, non_blocking=True)
         st_h = st.cpu()                                            # synchronises the stream: every copy above is complete
         a64, a32 = h64.numpy(), h32.numpy()
         res = {"chan": a64[:3], "status": st_h.numpy(), "F": a64[3:3 + len(f_rows)] if F is not None else None,

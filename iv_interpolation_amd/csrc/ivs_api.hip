@@ -11,6 +11,7 @@
 #include "ivs_bridge.hpp"
 #include "ivs_candles.hpp"
 #include "ivs_interp1d.hpp"
+#include "ivs_frame.hpp"
 #include "ivs_surface_dense.hpp"
 #include "ivs_surface_dense_var2.hpp"
 #include "ivs_surface_pass.hpp"
@@ -228,6 +229,91 @@ int ivs_frame_rows(const int64_t* q_off, int64_t n_series, int64_t total_queries
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(ivs::frame_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return check_launch("frame_rows_kernel");
+}
+
+namespace {
+__global__ __launch_bounds__(256) void i64_to_f64_kernel(const int64_t* a, double* o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = (double)a[i];
+}
+}  // namespace
+
+size_t ivs_frame_workspace_bytes(int64_t total_src, int64_t n_series, int32_t n_channels) {
+    if (total_src < 0 || n_series < 0 || n_channels < 0) return 0;
+    // the 1-D workspace, the positions as doubles, the channels' knot-rank tables
+    return ((ivs::interp1d_ws_bytes(total_src, n_series, n_channels) + 63) & ~(size_t)63) + (size_t)total_src * 8 +
+           (size_t)n_channels * (size_t)total_src * 4 + 64;
+}
+
+int ivs_frame_columns_f64(const ivs_frame_args* a, void* workspace, size_t workspace_bytes, void* stream) {
+    const char* fn = "ivs_frame_columns_f64";
+    g_err[0] = 0;
+    if (!a) return fail(IVS_EINVAL, "%s: null args", fn);
+    if (!valid_method(a->method)) return fail(IVS_EINVAL, "%s: unknown method %d", fn, a->method);
+    if (a->n_series < 0 || a->total_src < 0 || a->total_queries < 0 || a->n_channels < 0 || a->n_valid < 0 || a->n_f < 0 ||
+        a->n_c < 0 || a->n_idx < 0)
+        return fail(IVS_EINVAL, "%s: negative size", fn);
+    if (a->n_series == 0 || a->total_queries == 0) return IVS_OK;
+    if (!a->src_pos || !a->src_off || !a->q_off) return fail(IVS_EINVAL, "%s: null offsets / positions", fn);
+    if (a->n_channels > 0 && (!a->yk || !a->chan_out || !a->status)) return fail(IVS_EINVAL, "%s: null channel arrays", fn);
+    if (a->n_channels > 0 && (a->yk_stride < a->total_src || a->chan_stride < a->total_queries))
+        return fail(IVS_EINVAL, "%s: channel stride smaller than row length", fn);
+    if (a->n_valid > 0 && (!a->valid || a->valid_stride < a->total_src)) return fail(IVS_EINVAL, "%s: null / short validity rows", fn);
+    if (a->n_f > 0 && (!a->fsrc || !a->f_rows || !a->f_out || a->f_stride < a->total_queries || a->fsrc_stride < a->total_src))
+        return fail(IVS_EINVAL, "%s: bad f64 column arguments", fn);
+    if (a->n_c > 0 && (!a->csrc || !a->c_rows || !a->c_out || a->c_stride < a->total_queries || a->csrc_stride < a->total_src))
+        return fail(IVS_EINVAL, "%s: bad code column arguments", fn);
+    if (a->n_idx > 0 && (!a->idx_rows || !a->idx_out || a->idx_stride < a->total_queries)) return fail(IVS_EINVAL, "%s: bad index row arguments", fn);
+    if (a->date_ns && (!a->keep || !a->first_ns)) return fail(IVS_EINVAL, "%s: date_ns needs keep and first_ns", fn);
+    if (a->sym_col >= a->n_c) return fail(IVS_EINVAL, "%s: sym_col outside the code columns", fn);
+    if (a->greeks) {
+        if (a->greeks_stride < a->total_queries) return fail(IVS_EINVAL, "%s: short greeks output", fn);
+        if (a->ch_iv < 0 || a->ch_iv >= a->n_channels || a->ch_underlying < 0 || a->ch_underlying >= a->n_channels || a->ch_ttm < 0 ||
+            a->ch_ttm >= a->n_channels || a->n_channels > 3)
+            return fail(IVS_EINVAL, "%s: Greeks need the three channels iv / underlying / ttm", fn);
+        if (a->g_strike >= a->n_valid || a->g_rate >= a->n_valid || a->g_put >= a->n_valid) return fail(IVS_EINVAL, "%s: Greek validity row outside valid", fn);
+        if ((a->g_strike >= 0 && !a->strike_src) || (a->g_rate >= 0 && !a->rate_src) || (a->g_put >= 0 && !a->put_src))
+            return fail(IVS_EINVAL, "%s: a present column needs its source array", fn);
+    }
+    if (a->total_src > 0x7fffffffLL || a->n_series * (int64_t)(a->n_channels > 0 ? a->n_channels : 1) > 0x7fffffffLL ||
+        (a->total_queries + ivs::FR_ROWS - 1) / ivs::FR_ROWS > 0x7fffffffLL)
+        return fail(IVS_ERANGE, "%s: batch too large for one launch", fn);
+    const size_t need = ivs_frame_workspace_bytes(a->total_src, a->n_series, a->n_channels);
+    if (!workspace || workspace_bytes < need) return fail(IVS_ENOMEM, "%s: workspace %zu < %zu bytes", fn, workspace ? workspace_bytes : (size_t)0, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ivs::Interp1dParams p{};
+    double* w = static_cast<double*>(workspace);
+    const size_t plane = (size_t)a->n_channels * (size_t)a->total_src;
+    p.wx = w; p.wy = w + plane; p.ws = w + 2 * plane; p.wcp = w + 3 * plane;
+    p.wn = reinterpret_cast<int32_t*>(w + 4 * plane);
+    double* xk = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) + ((ivs::interp1d_ws_bytes(a->total_src, a->n_series, a->n_channels) + 63) & ~(size_t)63));
+    p.wr = reinterpret_cast<int32_t*>(xk + a->total_src);
+    p.xk = xk; p.yk = a->yk; p.yk_stride = a->yk_stride; p.knot_off = a->src_off;
+    p.S = a->n_series; p.C = a->n_channels; p.total_knots = a->total_src;
+    p.xq = nullptr; p.q_off = a->q_off; p.total_q = a->total_queries;
+    p.out = a->chan_out; p.out_stride = a->chan_stride; p.status = a->status; p.method = a->method;
+    p.greeks = nullptr;
+    if (a->total_src > 0) {
+        int64_t cb = (a->total_src + 255) / 256;
+        const int64_t cap = (int64_t)num_cu() * 16;
+        if (cb > cap) cb = cap;
+        hipLaunchKernelGGL(i64_to_f64_kernel, dim3((unsigned)cb), dim3(256), 0, st, a->src_pos, xk, a->total_src);
+    }
+    if (a->n_channels > 0) {
+        hipLaunchKernelGGL(ivs::interp1d_prepare_kernel, dim3((unsigned)(a->n_series * a->n_channels)), dim3(256), 0, st, p);
+        const int rc = check_launch("interp1d_prepare_kernel");
+        if (rc) return rc;
+    }
+    ivs::FrameParams f{};
+    f.src_pos = a->src_pos; f.src_off = a->src_off; f.q_off = a->q_off; f.S = a->n_series; f.total_src = a->total_src; f.total_q = a->total_queries;
+    f.valid = a->valid; f.valid_stride = a->valid_stride; f.n_valid = a->n_valid;
+    f.fsrc = a->fsrc; f.fsrc_stride = a->fsrc_stride; f.f_rows = a->f_rows; f.n_f = a->n_f; f.f_out = a->f_out; f.f_stride = a->f_stride;
+    f.csrc = a->csrc; f.csrc_stride = a->csrc_stride; f.c_rows = a->c_rows; f.n_c = a->n_c; f.c_out = a->c_out; f.c_stride = a->c_stride;
+    f.idx_rows = a->idx_rows; f.n_idx = a->n_idx; f.idx_out = a->idx_out; f.idx_stride = a->idx_stride;
+    f.first_ns = a->first_ns; f.needs = a->needs; f.sym_col = a->sym_col; f.date_ns = a->date_ns; f.keep = a->keep;
+    f.g_strike = a->g_strike; f.g_rate = a->g_rate; f.g_put = a->g_put; f.strike_src = a->strike_src; f.rate_src = a->rate_src; f.put_src = a->put_src;
+    f.ch_iv = a->ch_iv; f.ch_S = a->ch_underlying; f.ch_T = a->ch_ttm; f.greeks = a->greeks; f.greeks_stride = a->greeks_stride;
+    hipLaunchKernelGGL(ivs::frame_fused_kernel, dim3((unsigned)((a->total_queries + ivs::FR_ROWS - 1) / ivs::FR_ROWS)), dim3(256), 0, st, f, p);
+    return check_launch("frame_fused_kernel");
 }
 
 int ivs_candle_aggregate_f64(const int64_t* ts_ns, const double* open, const double* high, const double* low,

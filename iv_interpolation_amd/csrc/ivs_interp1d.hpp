@@ -19,6 +19,8 @@ struct Interp1dParams {
     const double* xq; const int64_t* q_off; int64_t total_q;
     double* out; int64_t out_stride; int32_t* status; int method;
     double* wx; double* wy; double* ws; double* wcp; int32_t* wn;
+    int32_t* wr;     // optional [C][total_knots]: valid knots of the channel among the series' rows 0..i (the fused frame pass turns a
+                     // source-row interval into the channel's knot interval with it: no per-channel search); nullptr: not written
     // optional Greeks epilogue (config.interpolation.preserve_greeks; greeks == nullptr: off).  The channel values of a row are
     // still in registers when its delta..rho are formed; strike / interest_rate / callput come from the source rows
     // through the forward-fill gather index (rows fi_* of fidx; -1 = column absent: strike -> NaN Greeks, rate -> 0.0,
@@ -148,10 +150,9 @@ __global__ __launch_bounds__(256) void interp1d_prepare_kernel(Interp1dParams p)
         __syncthreads();
         int pre = 0, tot = 0;
         for (int w = 0; w < 4; ++w) { int cw = wave_cnt[w]; if (w < wave) pre += cw; tot += cw; }
-        if (valid) {
-            int64_t r = base + pre + __popcll(m & ((1ull << lane) - 1ull));
-            wx[r] = x[i]; wy[r] = v;
-        }
+        const int64_t rk = base + pre + __popcll(m & ((1ull << lane) - 1ull));
+        if (valid) { wx[rk] = x[i]; wy[rk] = v; }
+        if (p.wr && i < n) p.wr[(int64_t)c * p.total_knots + a + i] = (int32_t)(rk + (valid ? 1 : 0));
         base += tot;
         __syncthreads();
     }

@@ -266,6 +266,83 @@ def frame_rows(q_off, first_ns, chan, sym_code, status, needs, stream=None):
     return dates, keep
 
 
+def frame_columns(src_pos, src_off, q_off, total_q: int, yk, method, valid, fsrc, f_rows, csrc, c_rows, idx_rows,
+                  first_ns=None, needs=None, sym_col: int = -1, greek=None, stream=None):
+    """The long output frame in ONE pass over its rows (ivs_frame_columns_f64): channels on the integer lattice, the
+    forward-filled f64 / code columns gathered straight from their source columns, raw gather-index rows for the columns the
+    host gathers itself, the date column and the dropna keep flag, optionally the Greeks -- what interp1d_batch +
+    ffill_index_batch + gather_rows (x2) + frame_rows do together, without the index arrays in between.
+
+    src_pos int64 [n_src], src_off / q_off int64 [S+1], yk float64 [C, n_src], valid uint8 [V, n_src], fsrc float64
+    [nF, n_src], csrc int32 [nC, n_src]; f_rows / c_rows / idx_rows: int32 device tensors naming the validity row of each
+    column (or None); first_ns int64 [S] + needs uint8 [S, C] switch the date / keep outputs on; greek = (g_rows (3 ints, -1
+    = column absent), strike_src, rate_src, put_src) or None.
+    Returns dict(chan [C,total_q], status [S,C], F, C, idx, date_ns, keep, greeks) of device tensors (None where not asked)."""
+    torch = require_device()
+    lib = _lib.load()
+    code = _lib.method_code(method) if isinstance(method, str) else int(method)
+    dev = yk.device
+    yk = _f64(torch, yk, "yk")
+    Cn, n_src = yk.shape
+    S = src_off.numel() - 1
+    total_q = int(total_q)
+    a = _lib.FrameArgs()
+    keepalive = []
+
+    def cont(t):
+        t = t.contiguous(); keepalive.append(t); return t
+    src_pos, src_off, q_off = cont(src_pos), cont(src_off), cont(q_off)
+    a.src_pos, a.src_off, a.q_off = _ptr(src_pos), _ptr(src_off), _ptr(q_off)
+    a.n_series, a.total_src, a.total_queries = S, n_src, total_q
+    a.yk, a.yk_stride, a.n_channels, a.method = _ptr(yk), n_src, Cn, code
+    chan = torch.empty((Cn, total_q), dtype=torch.float64, device=dev)
+    status = torch.zeros((S, Cn), dtype=torch.int32, device=dev)
+    a.chan_out, a.chan_stride, a.status = _ptr(chan), total_q, _ptr(status)
+    nV = 0 if valid is None else valid.shape[0]
+    if nV:
+        valid = cont(valid)
+    a.valid, a.valid_stride, a.n_valid = (_ptr(valid) if nV else 0), n_src, nV
+    F = Cc = idx = None
+    nF = 0 if fsrc is None else fsrc.shape[0]
+    if nF:
+        fsrc, f_rows = cont(fsrc), cont(f_rows)
+        F = torch.empty((nF, total_q), dtype=torch.float64, device=dev)
+        a.fsrc, a.fsrc_stride, a.f_rows, a.n_f, a.f_out, a.f_stride = _ptr(fsrc), n_src, _ptr(f_rows), nF, _ptr(F), total_q
+    nC = 0 if csrc is None else csrc.shape[0]
+    if nC:
+        csrc, c_rows = cont(csrc), cont(c_rows)
+        Cc = torch.empty((nC, total_q), dtype=torch.int32, device=dev)
+        a.csrc, a.csrc_stride, a.c_rows, a.n_c, a.c_out, a.c_stride = _ptr(csrc), n_src, _ptr(c_rows), nC, _ptr(Cc), total_q
+    nI = 0 if idx_rows is None else idx_rows.numel()
+    if nI:
+        idx_rows = cont(idx_rows)
+        idx = torch.empty((nI, total_q), dtype=torch.int32, device=dev)
+        a.idx_rows, a.n_idx, a.idx_out, a.idx_stride = _ptr(idx_rows), nI, _ptr(idx), total_q
+    dates = keep = None
+    a.sym_col = int(sym_col)
+    if first_ns is not None:
+        first_ns, needs = cont(first_ns), cont(needs)
+        dates = torch.empty(total_q, dtype=torch.int64, device=dev)
+        keep = torch.empty(total_q, dtype=torch.uint8, device=dev)
+        a.first_ns, a.needs, a.date_ns, a.keep = _ptr(first_ns), _ptr(needs), _ptr(dates), _ptr(keep)
+    greeks = None
+    a.g_strike = a.g_rate = a.g_put = -1
+    if greek is not None:
+        g_rows, ksrc, rsrc, psrc = greek
+        ksrc, rsrc, psrc = cont(ksrc), cont(rsrc), cont(psrc)
+        greeks = torch.empty((5, total_q), dtype=torch.float64, device=dev)
+        a.g_strike, a.g_rate, a.g_put = (int(x) for x in g_rows)
+        a.strike_src, a.rate_src, a.put_src = _ptr(ksrc), _ptr(rsrc), _ptr(psrc)
+        a.ch_iv, a.ch_underlying, a.ch_ttm = 0, 1, 2
+        a.greeks, a.greeks_stride = _ptr(greeks), total_q
+    wsb = lib.ivs_frame_workspace_bytes(n_src, S, Cn)
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+    rc = lib.ivs_frame_columns_f64(a, _ptr(ws), ws.numel() * 8, _stream(torch, stream))
+    _hold_for_stream(torch, stream, ws, chan, status, F, Cc, idx, dates, keep, greeks, *keepalive)
+    _lib.check(rc, "ivs_frame_columns_f64")
+    return {"chan": chan, "status": status, "F": F, "C": Cc, "idx": idx, "date_ns": dates, "keep": keep, "greeks": greeks}
+
+
 def bs_greeks(S, K, T, r, sigma, is_put=None, default_is_put: bool = False, stream=None):
     """Black-Scholes Greeks on the device.  All inputs CUDA float64 tensors of one shape (is_put: uint8 or None).
     Returns dict(delta, gamma, theta, vega, rho) of tensors with that shape."""

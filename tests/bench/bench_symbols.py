@@ -34,7 +34,30 @@ for _ in range(10): dev_step()
 e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 10
 bytes_ = S * (8 * n * 4 + 9 * n + 8 * n) + S * m * (3 * 8 + 9 * 4)       # knots + masks in, 3 f64 + 9 int32 index columns out
 res = {"workload": f"{S} symbols x {n} hourly rows -> {m} minute rows, 3 channels + 9 ffill index columns", "method": a.method,
-       "device": {"ms": ms, "symbols_per_s": S / ms * 1e3, "rows_per_s": S * m / ms * 1e3, "GBps": bytes_ / ms / 1e6, "frac_of_8TBps": bytes_ / ms / 1e6 / 8000}}
+       "device": {"ms": ms, "symbols_per_s": S / ms * 1e3, "rows_per_s": S * m / ms * 1e3, "GBps": bytes_ / ms / 1e6, "frac_of_8TBps": bytes_ / ms / 1e6 / 8000,
+                  "note": "rounds 1-2 yardstick: interp1d_batch + ffill_index_batch only (the index columns are an intermediate)"}}
+# ---- the whole device side of interpolate_frame: 3 channels, 7 forward-filled f64 columns, 2 code columns (symbol,
+# callput), the date column and the keep flag -- ALGORITHMIC bytes = what the long frame needs written + the sources read
+fsrc = d(r.normal(size=(7, S * n))); f_rows = d(np.arange(2, 9, dtype=np.int32))
+csrc = d(r.integers(0, 5, (2, S * n)).astype(np.int32)); c_rows = d(np.array([0, 1], np.int32))
+first_ns = d((np.arange(S) * 86_400_000_000_000).astype(np.int64)); needs = d(np.ones((S, 3), np.uint8))
+row_bytes = 3 * 8 + 7 * 8 + 2 * 4 + 8 + 1
+bytes_f = S * n * (8 + 3 * 8 + 9 + 7 * 8 + 2 * 4) + S * m * row_bytes
+def fused_step():
+    return engine.frame_columns(pos, koff_d, qoff_d, S * m, yk_d, a.method, valid, fsrc, f_rows, csrc, c_rows, None, first_ns, needs, 0)
+def separate_step():
+    out, st = engine.interp1d_batch(xk_d, yk_d, koff_d, qoff_d, S * m, a.method)
+    fidx = engine.ffill_index_batch(pos, koff_d, valid, qoff_d, S * m)
+    F = engine.gather_rows(fsrc, fidx, f_rows); Cc = engine.gather_rows(csrc, fidx, c_rows)
+    return engine.frame_rows(qoff_d, first_ns, out, Cc[0], st, needs)
+for name, fn in (("device_frame_fused", fused_step), ("device_frame_separate_calls", separate_step)):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize(); msf = e0.elapsed_time(e1) / 10
+    res[name] = {"ms": msf, "symbols_per_s": S / msf * 1e3, "rows_per_s": S * m / msf * 1e3, "algorithmic_bytes": bytes_f,
+                 "GBps": bytes_f / msf / 1e6, "frac_of_8TBps": bytes_f / msf / 1e6 / 8000,
+                 "columns": "3 channels + 7 f64 + 2 code columns forward-filled + date + keep = %d B per output row" % row_bytes}
 frames = [synthetic_symbol(f"s{i}", n, seed=i) for i in range(a.e2e)]
 iv = IVInterpolator(a.method)
 iv.interpolate_batch(frames[:8])

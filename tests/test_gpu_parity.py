@@ -903,3 +903,71 @@ def test_fill_methods_1d_batch_vs_oracle(method):
     ref, rst = O.interp1d_batch(xk, yk, koff, None, qoff, METHODS[method])
     assert np.array_equal(st.cpu().numpy(), rst)
     assert np.array_equal(out.cpu().numpy(), ref, equal_nan=True)
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic", "pchip", "pad", "bfill", "krogh"])
+def test_fused_frame_pass_equals_the_separate_calls(method):
+    """ivs_frame_columns_f64 (one pass over the output rows) against the five calls it replaces -- interp1d[_greeks]_batch,
+    ffill_index_batch, gather_rows x2, frame_rows -- bit for bit: symbols of 1..700 source rows (beyond 512 staged rows a
+    block takes the per-row path), tiny symbols (many per block), sparse validity, a first source row that is NOT at
+    position 0, duplicate-style consecutive positions, and the Greeks epilogue."""
+    import torch
+    from iv_interpolation_amd import engine
+    r = np.random.default_rng(4242)
+    sizes = np.concatenate([r.integers(1, 6, 40), r.integers(10, 90, 60), [700, 530, 3, 64, 64, 64]])
+    r.shuffle(sizes)
+    S = len(sizes)
+    pos_l, m_l = [], []
+    for k, n in enumerate(sizes):
+        gaps = r.choice([1, 1, 2, 7, 60, 60, 60], n)             # consecutive positions = duplicate timestamps (R7)
+        p = np.cumsum(gaps) - gaps[0] + (3 if k % 17 == 5 else 0)   # a few symbols start at position 3, not 0
+        pos_l.append(p); m_l.append(int(p[-1]) + 1 + int(r.integers(0, 5)))
+    src_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    q_off = np.concatenate([[0], np.cumsum(m_l)]).astype(np.int64)
+    pos = np.concatenate(pos_l).astype(np.int64)
+    n_src, total_q = int(src_off[-1]), int(q_off[-1])
+    yk = r.normal(0.6, 0.1, (3, n_src)); yk[1] = 25000 + 100 * yk[1]; yk[2] = np.abs(yk[2]) * 0.1 + 0.01
+    yk[r.random(yk.shape) < 0.25] = np.nan
+    yk[0, src_off[7]:src_off[8]] = np.nan
+    nV = 9
+    valid = (r.random((nV, n_src)) > 0.3).astype(np.uint8); valid[4] = 0; valid[5] = 1
+    fsrc = r.normal(size=(5, n_src)); f_rows = np.array([1, 2, 3, 4, 5], np.int32)
+    csrc = r.integers(0, 50, (2, n_src)).astype(np.int32); c_rows = np.array([0, 6], np.int32)
+    host_rows = np.array([7, 8], np.int32)
+    first_ns = (r.integers(0, 10**6, S) * 60_000_000_000).astype(np.int64)
+    needs = (r.random((S, 3)) < 0.7).astype(np.uint8)
+    gvalid = (r.random((3, n_src)) > 0.2).astype(np.uint8)
+    ksrc = r.uniform(20000, 30000, n_src); rsrc = r.uniform(0, 0.05, n_src); psrc = r.integers(0, 3, n_src).astype(np.uint8)
+    d = dev
+    ko, qo, pos_d, yk_d = d(src_off), d(q_off), d(pos), d(yk)
+    vall = np.concatenate([valid, gvalid])
+    got = engine.frame_columns(pos_d, ko, qo, total_q, yk_d, method, d(vall), d(fsrc), d(f_rows), d(csrc), d(c_rows), d(host_rows),
+                               d(first_ns), d(needs), 0, ((nV, nV + 1, nV + 2), d(ksrc), d(rsrc), d(psrc)))
+    torch.cuda.synchronize()
+    fidx = engine.ffill_index_batch(pos_d, ko, d(valid), qo, total_q)
+    gidx = engine.ffill_index_batch(pos_d, ko, d(gvalid), qo, total_q)
+    out, st, gr = engine.interp1d_greeks_batch(pos_d.to(torch.float64), yk_d, ko, qo, total_q, method, (0, 1, 2), gidx, (0, 1, 2),
+                                               d(ksrc), d(rsrc), d(psrc))
+    F = engine.gather_rows(d(fsrc), fidx, d(f_rows)); Cc = engine.gather_rows(d(csrc), fidx, d(c_rows))
+    dts, kp = engine.frame_rows(qo, d(first_ns), out, Cc[0], st, d(needs))
+    torch.cuda.synchronize()
+    eq = lambda a, b: np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)      # noqa: E731
+    assert eq(got["status"], st)
+    assert eq(got["chan"], out), method
+    assert eq(got["F"], F) and eq(got["C"], Cc)
+    assert eq(got["idx"], fidx[torch.from_numpy(host_rows.astype(np.int64)).cuda()])
+    assert eq(got["date_ns"], dts) and eq(got["keep"], kp)
+    assert eq(got["greeks"], gr)
+    # and the channels against the oracle (the separate calls are pinned elsewhere; this pins the fused pass directly)
+    ref, rst = O.interp1d_batch(pos.astype(np.float64), yk, src_off, None, q_off, O.METHOD_CODES[method])
+    g = got["chan"].cpu().numpy()
+    ks = np.repeat(np.arange(S), sizes); gpos = q_off[:-1][ks] + pos
+    for c in range(3):                                            # knot rows keep their source cell in `chan` ...
+        okk = ~np.isnan(yk[c]) & (rst[ks, c] != O.ST_ILL_CONDITIONED)      # ... unless the polynomial was refused (> 32 knots)
+        ref[c, gpos[okk]] = yk[c][okk]
+    assert np.array_equal(np.isnan(g), np.isnan(ref))
+    if method in ("linear", "pad", "bfill"):
+        assert np.array_equal(g, ref, equal_nan=True)
+    else:
+        sc = np.nanmax(np.abs(ref), axis=1, keepdims=True)
+        assert np.nanmax(np.abs(g - ref) / sc) < (1e-9 if method == "krogh" else 1e-12)
