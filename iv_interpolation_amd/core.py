@@ -277,6 +277,9 @@ class IVInterpolator:
 
     def interpolate_batch(self, frames: Sequence[pd.DataFrame]) -> List[Optional[pd.DataFrame]]:
         """Many symbols, one device round trip.  Element i is what interpolate_symbol(frames[i]) returns."""
+        fast = self._batch_via_frame(frames)
+        if fast is not None:
+            return fast
         preps: List[Optional[_Prepared]] = []
         for f in frames:
             try:
@@ -332,6 +335,50 @@ class IVInterpolator:
                 results[i] = None
         return results
 
+    def _batch_via_frame(self, frames) -> Optional[List[Optional[pd.DataFrame]]]:
+        """interpolate_batch through the columnar path: the frames become ONE long frame grouped by frame
+        number, one pass of vectorised bookkeeping and one device round trip, the result is cut back into per-symbol frames
+        (views of the long result).  Only for the plain case -- at least 4 frames with identical columns and dtypes, a
+        datetime64 date column, an implemented method; anything else (and any frame the long frame cannot represent
+        exactly) goes through the per-symbol bookkeeping, which is the reference's contract statement by statement."""
+        if len(frames) < 4:
+            return None
+        try:
+            code = method_code(self.method)
+        except KeyError:
+            return None
+        f0 = frames[0]
+        if not isinstance(f0, pd.DataFrame) or "date" not in f0.columns or any(c not in f0.columns for c in REQUIRED):
+            return None
+        if not str(f0["date"].dtype).startswith("datetime64") or f0.columns.duplicated().any():
+            return None
+        c0, dt0 = f0.columns, list(f0.dtypes)
+        for f in frames:                                                 # same columns in the same order (pd.concat would align by name)
+            if not isinstance(f, pd.DataFrame) or not (f.columns is c0 or f.columns.equals(c0)):
+                return None
+        lens = np.array([len(f) for f in frames], np.int64)
+        if int(lens.sum()) == 0:
+            return None
+        data = pd.concat(frames, ignore_index=True, copy=False)
+        if list(data.dtypes) != dt0 or any(list(f.dtypes) != dt0 for f in frames):      # one schema for all (dtype rules are per symbol)
+            return None
+        grp = np.repeat(np.arange(len(frames), dtype=np.int64), lens)
+        be = self._backend or HipBackend()
+        try:
+            out = self._frame_impl(data, grp, len(frames), lens, None, be, code, split=True)
+        except EngineUnavailable:
+            raise
+        except Exception as e:                                           # anything unusual: the per-symbol bookkeeping decides
+            logger.debug(f"columnar batch path declined: {e}")
+            return None
+        redo = [i for i, r in enumerate(out) if r is NotImplemented]
+        if redo:
+            keep_be, self_fast = self._backend, None
+            single = IVInterpolator(self.method, self.min_points, backend=keep_be, preserve_greeks=self.preserve_greeks)
+            for i in redo:
+                out[i] = single.interpolate_batch([frames[i]])[0]
+        return out
+
     def interpolate_frame(self, data: pd.DataFrame) -> pd.DataFrame:
         """Columnar ingest/egress: ALL symbols of one long frame -- what the reference reads
         with ``SELECT ... FROM trading_tickers ORDER BY symbol, date`` -- in one pass of vectorised NumPy bookkeeping
@@ -358,12 +405,20 @@ class IVInterpolator:
             cols_e += [] if "is_interpolated" in cols_e else ["is_interpolated"]
             return pd.DataFrame({c: pd.Series(dtype=("datetime64[ns]" if c == "date" else bool if c == "is_interpolated"
                                                      else data[c].dtype)) for c in cols_e})
+        sym_codes, sym_uniques = pd.factorize(data["symbol"], sort=True)
+        return self._frame_impl(data, sym_codes, len(sym_uniques), None, (sym_codes, sym_uniques), be, code)
+
+    def _frame_impl(self, data, grp, n_grp, grp_len, sym_fact, be, code, split=False):
+        """The columnar path on EXPLICIT groups: `grp` [rows] = group number of every row of `data` (-1: ignored), groups
+        in output order.  interpolate_frame groups by the symbol column (sym_fact = its factorisation, reused for the
+        column's codes); interpolate_batch groups by frame number (grp_len = the frames' lengths for the min_points guard,
+        the symbol column is then just another forward-filled column).  split: return the per-group results as a list."""
         cols_in = [c for c in data.columns if c != "date"]
         out_cols = ["date"] + cols_in + (["is_interpolated"] if "is_interpolated" not in cols_in else [])
         d_idx = pd.DatetimeIndex(pd.to_datetime(data["date"]))
         tz = d_idx.tz
         d_ns = d_idx.as_unit("ns").asi8
-        sym_codes, sym_uniques = pd.factorize(data["symbol"], sort=True)
+        sym_codes = grp
         ok_row = (sym_codes >= 0) & ~np.asarray(d_idx.isna())
         rows = np.flatnonzero(ok_row)
         rows = rows[np.lexsort((d_ns[rows], sym_codes[rows]))]          # by symbol, then date (stable)
@@ -380,25 +435,26 @@ class IVInterpolator:
                 grp = np.sort(rows[lo_:hi_])                             # the symbol's rows in input order
                 rows[lo_:hi_] = grp[np.argsort(d64[grp], kind="quicksort")]
             dn = d_ns[rows]
-        S_all = len(sym_uniques)
+        S_all = int(n_grp)
         empty = pd.DataFrame({c: pd.Series(dtype=(bool if c == "is_interpolated" else data[c].dtype if c in data.columns else "float64"))
                               for c in out_cols})
         if len(rows) == 0:
-            return empty
+            return [None] * S_all if split else empty
         start = np.searchsorted(sc, np.arange(S_all), side="left")
         count = np.searchsorted(sc, np.arange(S_all), side="right") - start
         present = count > 0
         first_ns = np.where(present, dn[np.minimum(start, len(dn) - 1)], 0)
         last_ns = np.where(present, dn[np.minimum(start + count - 1, len(dn) - 1)], 0)
         span = last_ns - first_ns
-        keep_sym = present & (count >= self.min_points) & (span <= 30 * 24 * 3600 * 1_000_000_000)   # core.py:26-28, 36-39
+        n_rows_grp = count if grp_len is None else np.asarray(grp_len, np.int64)                     # len(symbol_data), core.py:26
+        keep_sym = present & (n_rows_grp >= self.min_points) & (span <= 30 * 24 * 3600 * 1_000_000_000)   # core.py:26-28, 36-39
         m0 = span // MINUTE_NS + 1
         keep_sym &= m0 <= 100000                                                                     # core.py:49-51
         rel = dn - first_ns[sc]
         on = keep_sym[sc] & (rel % MINUTE_NS == 0)                        # off-lattice rows vanish (R6)
         ridx = np.flatnonzero(on)
         if len(ridx) == 0:
-            return empty
+            return [None] * S_all if split else empty
         rsym = sc[ridx]; lat = rel[ridx] // MINUTE_NS
         # compact symbol numbering over the kept symbols
         kept = np.flatnonzero(keep_sym)
@@ -441,8 +497,8 @@ class IVInterpolator:
                 else np.zeros((0, len(src_rows))))
         cats, codes = {}, []
         for c in o_names:
-            if c == "symbol":
-                cd, cat = sym_codes[src_rows].astype(np.int32), np.asarray(sym_uniques, dtype=object)
+            if c == "symbol" and sym_fact is not None:
+                cd, cat = sym_fact[0][src_rows].astype(np.int32), np.asarray(sym_fact[1], dtype=object)
             else:
                 cd, cat = pd.factorize(src_np[c], use_na_sentinel=True)
                 cd = cd.astype(np.int32); cat = np.asarray(cat, dtype=object)
@@ -537,9 +593,38 @@ class IVInterpolator:
                 if gname not in out_cols:
                     out_cols.append(gname)
         res = pd.DataFrame({c: cols[c] for c in out_cols}, copy=False)
-        if not keep.all():
-            res = res[keep].reset_index(drop=True)
-        return res
+        if not split:
+            if not keep.all():
+                res = res[keep].reset_index(drop=True)
+            return res
+        # per-group results (interpolate_batch): slices of the long frame, indexed by merged-frame position like the
+        # per-symbol path (core.py:74 leaves the surviving positions as the index).  A symbol whose int / bool columns
+        # could stay integral (no row missing in ITS merged frame) while the long frame's did not is left to the caller.
+        results = [None] * S_all
+        int_cols = any(src_np[c].dtype.kind in "iub" for c in cols_in)
+        kall = bool(keep.all())
+        for k, gid in enumerate(kept):
+            a, b = int(q_off[k]), int(q_off[k + 1])
+            if not sym_ok[k]:
+                continue                                              # scipy would have raised: None (core.py:83-85)
+            if int_cols and M[k] == q[k] and not nothing_missing:
+                results[gid] = NotImplemented                         # dtype differs from the long frame's: per-symbol path
+                continue
+            if kall:
+                sub = res.iloc[a:b]; sub.index = pd.RangeIndex(b - a)
+            else:
+                kk = keep[a:b]
+                nk = int(kk.sum())
+                if nk == 0:
+                    continue                                          # "No valid data after interpolation" (core.py:76-78)
+                lo_ = int(kk.argmax()); hi_ = b - a - int(kk[::-1].argmax())
+                if hi_ - lo_ == nk:                                   # the usual case: leading / trailing rows dropped
+                    sub = res.iloc[a + lo_:a + hi_]; sub.index = pd.RangeIndex(lo_, hi_)
+                else:
+                    sub = res.iloc[a:b]; sub.index = pd.RangeIndex(b - a); sub = sub[kk]
+            sub._is_copy = None       # a slice of a frame nobody else holds: callers add columns (batch_id) without pandas' view warning
+            results[gid] = sub
+        return results
 
     # ------------------------------------------------------------------ host bookkeeping
     def _prepare(self, symbol_data: pd.DataFrame) -> Optional[_Prepared]:

@@ -131,3 +131,35 @@ def test_polynomial_methods_give_up_beyond_32_knots(method):
     iv = IVInterpolator(method, 10, backend=OracleBackend())
     assert iv.interpolate_symbol(ok) is not None
     assert iv.interpolate_symbol(too_many) is None
+
+
+def test_interpolate_batch_columnar_path_against_reference_goldens():
+    """interpolate_batch on >= 4 frames with identical columns and dtypes takes the columnar path (one long frame grouped by
+    frame number, results cut back into per-symbol frames): every golden case, batched with the cases that share its method,
+    min_points and input schema, must come back exactly as the REAL reference returned it for the single symbol -- values,
+    dtypes, column order AND the surviving merged-frame positions as index; frames the long frame cannot represent fall
+    back to the per-symbol bookkeeping inside the call."""
+    groups = {}
+    for name in CASES.names():
+        c = CASES.cases[name]
+        groups.setdefault((c["method"], c["min_points"], tuple(map(tuple, c["in_columns"]))), []).append(name)
+    n_fast = n_cases = 0
+    for (method, min_points, _), names in groups.items():
+        if len(names) < 4:
+            continue
+        iv = IVInterpolator(method, min_points, backend=OracleBackend())
+        frames = [CASES.input(n) for n in names]
+        before = [f.copy(deep=True) for f in frames]
+        took_fast = iv._batch_via_frame(frames) is not None
+        got = iv.interpolate_batch(frames)
+        for n, g, f, b in zip(names, got, frames, before):
+            assert_symbol_frame(g, CASES.expected(n), name=f"batch[{method}/{min_points}] {n}", **method_tolerances(method))
+            pd.testing.assert_frame_equal(f, b)          # the caller's frames are not mutated
+        n_fast += took_fast; n_cases += len(names)
+        if took_fast and any(g is not None for g in got):      # the per-symbol frames accept the callers' new column silently
+            import warnings
+            g = next(x for x in got if x is not None)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                g["batch_id"] = "b1"                             # batch_processor.py:105, complete_pipeline.py:323
+    assert n_fast >= 8 and n_cases >= 120, (n_fast, n_cases)

@@ -2,8 +2,12 @@
 """Dense 64x16 kernel: throughput by input layout (shared vs per-surface maturities / query grids / strikes)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse
 import torch
 from iv_interpolation_amd import engine, synth
+ap = argparse.ArgumentParser(); ap.add_argument("--methods", default="cubic,pchip,linear"); ap.add_argument("--one-pass", action="store_true")
+ap.add_argument("--only", default="", help="substring filter on the case names")
+a = ap.parse_args()
 B = 1_000_000
 d = synth.torch_batch(B, 64, 16)
 Kq, Tq = synth.query_grids(64, 16); Kq = torch.from_numpy(Kq).cuda(); Tq = torch.from_numpy(Tq).cuda()
@@ -15,9 +19,11 @@ cases = {"shared T, Tq, Kq (benchmark layout)": (d["K"], d["T"], Kq, Tq),
          "per-surface T, Tq and Kq": (d["K"], Tb, Kqb, Tqb),
          "shared strikes (one K row)": (d["K"][0].contiguous(), d["T"], Kq, Tq),
          "strike rows in runs of 8 (snapshots of one chain)": (d["K"][(torch.arange(B, device="cuda") // 8) * 8].contiguous(), d["T"], Kq, Tq)}
-for method in ("cubic", "pchip", "linear"):
+for method in a.methods.split(","):
     for name, (K, T, kq, tq) in cases.items():
-        run = lambda: engine.surface_batch(K, T, d["sigma"], kq, tq, method, out=out, status=st)
+        if a.only and a.only not in name:
+            continue
+        run = lambda: engine.surface_batch(K, T, d["sigma"], kq, tq, method, out=out, status=st, one_pass=a.one_pass)
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
