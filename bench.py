@@ -180,6 +180,24 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
     for _ in range(warmup):
         step()
     kernel = engine.last_kernel()
+    launch = "eager"
+    eager_step = step
+    if a.launch == "graph":
+        # the call is allocation- and synchronisation-free (include/ivs.h), so its launches -- maturity tables, the surface
+        # kernel, the two filter passes -- replay as ONE hipGraph: the per-launch host cost and the gaps between dependent
+        # kernels (~30 us per call, 8 % of a 125 k-surface shard at N = 8) leave the timed region; same work, same kernels
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            step = graph.replay
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            launch = "hipGraph replay of one captured call"
+        except Exception as e:                                    # capture unavailable: time the eager call
+            launch = f"eager (graph capture failed: {type(e).__name__})"
+            step = eager_step
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     if dist:
@@ -223,7 +241,8 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
         def run_on(o):
             nonlocal out
             out = o
-            step()
+            eager_step()
+        step = eager_step                                          # a captured graph has its output buffer baked in
         best, more_ms = engine.place_output(run_on, tuple(first.shape), tries=a.placement_tries - 1)
         out = best
         t_spin = time.perf_counter()
@@ -252,7 +271,7 @@ def run_workload(torch, engine, synth, sharding, dist, a, workload, method, B_gl
     m = {
         "value": total * steps / wall, "ms_per_step": wall / steps * 1e3, "total_surfaces": total, "B_rank": B,
         "desc": desc, "kernel": kernel, "nK": nK, "nT": nT, "mK": mK, "mT": mT, "ragged": ragged, "sample": sample,
-        "placement": placement, "shard": [lo, hi], "per_rank_ms": per_rank_ms, "per_rank_B": per_rank_B, "ranks_seen": ranks_seen,
+        "placement": placement, "launch": launch, "shard": [lo, hi], "per_rank_ms": per_rank_ms, "per_rank_B": per_rank_B, "ranks_seen": ranks_seen,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(workload, method, kernel, B),
                      "kernel": kernel, "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms),
@@ -326,6 +345,8 @@ def main():
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="N > 1: after the timed region also time the kernel on the fastest of N - 1 further output allocations "
                          "(reported as roofline.frac_placed / value_with_placement, never as `value`)")
+    ap.add_argument("--launch", default="eager", choices=["eager", "graph"],
+                    help="graph: capture one call into a hipGraph after the warm-up and time its replays (same kernels, no per-launch host cost)")
     ap.add_argument("--spin-ms", type=float, default=100.0, help="untimed launches before the warm-up steps (clock ramp)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-4 / config-5 sub-results of the N = 1 line")
     ap.add_argument("--check", type=int, default=256, help="surfaces compared with the oracle after the timed region")
@@ -415,7 +436,8 @@ def main():
                        "quote_grid": [m["nK"], m["nT"]], "output_grid": [m["mK"], m["mT"]], "kernel": m["kernel"],
                        "sharding": shard_note + (", balanced by strike count" if m["ragged"] and scaling == "strong" and world > 1 else "")
                                    + ", no data-path collective",
-                       "ranks_seen_by_all_reduce": m["ranks_seen"], "seed": synth.BASE_SEED, "placement": m["placement"]},
+                       "ranks_seen_by_all_reduce": m["ranks_seen"], "seed": synth.BASE_SEED, "placement": m["placement"],
+                       "launch": m["launch"]},
             "roofline": roof,
             "parity_check": {},
         }
