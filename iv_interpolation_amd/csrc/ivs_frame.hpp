@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void frame_fused_kernel(FrameParams f, Interp1
     if (tid == 64) sh.s_edge[1] = series_of(f.q_off, f.S, g_last);
     __syncthreads();
     const int64_t s_first = sh.s_edge[0], s_last = sh.s_edge[1];
-    const int C = p.C, method = p.method;
+    const int C = p.C;
     const int nsym = (int)(s_last - s_first + 1 < FR_MAXSYM + 1 ? s_last - s_first + 1 : FR_MAXSYM + 1);
     // the WINDOW of source rows the block needs: whole symbols when they fit, else from the last source row at or before the
     // block's first row (in the first symbol) to the last source row at or before its last row (in the last symbol)

@@ -25,6 +25,8 @@ struct SurfaceParams {
     const void* tqs;     // dense kernels, T and Tq shared by the batch: TqShared tables in the caller's workspace (written by
                          // tq_tables_kernel on the same stream, read through the scalar cache)
     unsigned long long* queue;   // row-pass kernels: work-queue heads in the caller's workspace (zeroed by tq_tables_kernel), or nullptr
+    const int* mode;     // nullptr, or TqShared::mode (written by tq_tables_kernel): 1 = the 64 x 16 fast kernels return at once and
+                         // the compaction kernel takes every surface of the batch ("missing quotes first")
     int* redo;           // nullptr, or a counter in the caller's workspace (zeroed by tq_tables_kernel): the fast kernels count
                          // the surfaces they tag for a redo pass, and a FILTER pass whose counter is 0 returns at once instead
                          // of scanning B tags (two such scans were 1.7 % of a config-3 call with nothing to redo)

@@ -81,9 +81,16 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
     double xq = (kq_shared && act) ? p.Kq[lane] : nanv;
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
 
-    if (p.redo && *p.redo == 0) return;                    // nothing was tagged (wave-uniform)
+    const bool all = p.mode && *p.mode != 0;               // "missing quotes first": nothing was tagged, every surface is ours
+    if (!all && p.redo && *p.redo == 0) return;            // nothing was tagged (wave-uniform)
     bool told = false;
-    auto leave = [&]() { if (lane == 0 && p.redo && !told) { *reinterpret_cast<volatile int*>(p.redo + 1) = 1; told = true; } };      // the surface keeps its tag: generic kernel
+    double* tag_at = nullptr;                              // the current surface's first output cell
+    auto leave = [&]() {                                   // the surface keeps (or, in `all` mode, gets) its tag: generic kernel
+        if (lane == 0) {
+            if (all) reinterpret_cast<unsigned long long*>(tag_at)[0] = REDO_SENTINEL;
+            if (p.redo && !told) { *reinterpret_cast<volatile int*>(p.redo + 1) = 1; told = true; }
+        }
+    };
     const int64_t n_outer = (p.B + 63) / 64;
     // blocks of 64 tags are claimed from a work queue (head 16 of the workspace; WorkQueue, ivs_surface_generic.hpp): the
     // tagged surfaces are spread unevenly over the blocks, and so is the speed of the workgroups
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
     for (int64_t ob = p.queue ? wq.take() : (int64_t)blockIdx.x; ob >= 0 && ob < n_outer; ob = p.queue ? wq.take() : ob + gridDim.x) {
       const int64_t bi = ob * 64 + lane;
       const bool tagged = bi < p.B &&
-          reinterpret_cast<const unsigned long long*>(p.out + bi * (int64_t)mT * mK)[0] == REDO_SENTINEL;
+          (all || reinterpret_cast<const unsigned long long*>(p.out + bi * (int64_t)mT * mK)[0] == REDO_SENTINEL);
       unsigned long long todo = __ballot(tagged);
       // quotes and strikes of the NEXT tagged surface of the block are requested while the current one is processed
       double vn[DT], kn = 0.0;
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
         todo &= todo - 1;
         const int64_t b = ob * 64 + bit;
         double* outb = p.out + b * (int64_t)mT * mK;
+        tag_at = outb;
         double v[DT];
 #pragma unroll
         for (int t = 0; t < DT; ++t) v[t] = vn[t];
@@ -309,6 +317,14 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
     }
 }
 
+}  // namespace ivs
+#include "ivs_surface_masked_pass.hpp"      // the not-a-knot methods' row-pass form (needs the definitions above)
+namespace ivs {
+
+#ifndef IVS_MASKED_PASS
+#define IVS_MASKED_PASS 1      // 0: cubic / cubicspline on the two-lanes-per-row kernel above (A/B)
+#endif
+
 #ifndef IVS_DIAG_MINIMAL
 // Second pass behind the dense / row-pass kernel for uniform 64 x 16 batches: returns true when launched.
 inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
@@ -319,6 +335,13 @@ inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
     int64_t grid = (int64_t)cx.num_cu * (lerp ? 12 : 8);
     const int64_t work = (p.B + 63) / 64;
     if (grid > work) grid = work;
+    if (IVS_MASKED_PASS && (p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) {
+        int64_t g12 = (int64_t)cx.num_cu * 12;
+        if (g12 > work) g12 = work;
+        if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_CUBIC>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
+        else hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_CUBICSPLINE>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
+        return true;
+    }
     switch (p.method) {
 #define IVS_MASKED_CASE(M) case M: hipLaunchKernelGGL((surface_masked_kernel<M>), dim3((unsigned)grid), dim3(64), lds, cx.st, p); break;
         IVS_MASKED_CASE(IVS_LINEAR) IVS_MASKED_CASE(IVS_SLINEAR) IVS_MASKED_CASE(IVS_CUBIC) IVS_MASKED_CASE(IVS_CUBICSPLINE)

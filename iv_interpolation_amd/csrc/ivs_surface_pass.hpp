@@ -483,6 +483,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
 #ifdef IVS_PASS_ENDSTAMP
     if (threadIdx.x == 0 && d_pass_ends) d_pass_ends[blockIdx.x * 2] = wall_clock64();
 #endif
+    if (!VAR && p.mode && *((const int IVS_CONST*)p.mode)) return;      // "missing quotes first": the compaction kernel takes the batch
     using G = PassGeom<NKB, SL>;
     constexpr int RP = G::RP, NPASS = G::NPASS, KCAP = G::KCAP, RS = G::RS, TN = G::TN;
     // passes in flight per lane (8-knot segments, 64 strikes: a whole surface; the local-slope methods need the registers: one pass)
@@ -817,6 +818,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
         if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
         p.tqs = tq;
         p.redo = tq->redo;
+        p.mode = fixed64 ? &tq->mode : nullptr;
     } else {      // per-surface maturities: the T-phase runs inside the kernel; only the queue heads need zeroing
         if (hipMemsetAsync(tq->queue, 0, sizeof(TqShared::queue), st) != hipSuccess) return -1;
         p.tqs = nullptr;

@@ -971,3 +971,35 @@ def test_fused_frame_pass_equals_the_separate_calls(method):
     else:
         sc = np.nanmax(np.abs(ref), axis=1, keepdims=True)
         assert np.nanmax(np.abs(g - ref) / sc) < (1e-9 if method == "krogh" else 1e-12)
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic", "cubicspline", "pchip", "akima", "nearest", "quadratic"])
+def test_missing_quotes_first_mode(method):
+    """Batches of >= 4096 64 x 16 surfaces are probed by tq_tables_kernel (row 0 of 64 surfaces spread over the batch): when
+    at least half of the sampled surfaces lack a quote the fast kernel returns at once and the compaction kernel takes EVERY
+    surface ('missing quotes first').  Three batches against the oracle: (a) 10 % of all quotes missing (mode on), (b) quotes
+    missing ONLY in the sampled surfaces (mode on, 99 % of the surfaces are complete and still go through the compaction
+    kernel), (c) quotes missing everywhere EXCEPT in the sampled surfaces (mode off: tag + redo as before).  'quadratic'
+    has no compaction kernel: the mode must stay off for it."""
+    from iv_interpolation_amd import synth
+    import c_oracle
+    B = 6000
+    Kq, Tq = synth.query_grids(64, 16)
+    sampled = (np.arange(64) * (B // 64)).astype(np.int64)
+    r = np.random.default_rng(99)
+    for case in ("all", "sampled_only", "all_but_sampled"):
+        d = synth.numpy_batch(B, 64, 16, seed=synth.BASE_SEED + 70)
+        sg = d["sigma"]
+        if case == "all":
+            sg[r.random(sg.shape) < 0.1] = np.nan
+        elif case == "sampled_only":
+            sg[sampled, 0, 5] = np.nan; sg[sampled, 3, 40:44] = np.nan
+        else:
+            mask = r.random(sg.shape) < 0.1
+            mask[sampled] = False
+            sg[mask] = np.nan
+        sg[17, 2, :62] = np.nan                     # a row with two quotes: too few knots for cubic / akima / quadratic
+        got, st, kern = _run(d, Kq, Tq, method)
+        ref, rst = c_oracle.load().surface_batch(d["K"], d["T"], sg, Kq, Tq, METHODS[method])
+        assert np.array_equal(st, rst), (method, case)
+        close(got, ref, method, f"missing-quotes-first {case} {method} [{kern}]")

@@ -11,7 +11,7 @@ int ivs_surface_batch_f64(const double* K, const int64_t* k_off, int64_t k_strid
                           int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
     ivs::SurfaceParams p;
     p.K = K; p.k_off = k_off; p.k_stride = k_off ? 0 : k_stride; p.k_total = k_off ? k_stride : 0; p.nK = nK; p.T = T; p.t_stride = t_stride; p.nT = nT;
-    p.sigma = sigma; p.B = B; p.map_groups = 1; p.tqs = nullptr; p.redo = nullptr; p.queue = nullptr; p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;
+    p.sigma = sigma; p.B = B; p.map_groups = 1; p.tqs = nullptr; p.redo = nullptr; p.queue = nullptr; p.mode = nullptr; p.Kq = Kq; p.kq_stride = kq_stride; p.mK = mK;
     p.Tq = Tq; p.tq_stride = tq_stride; p.mT = mT; p.out = out; p.status = status; p.method = method;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t grid = 2048;

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from iv_interpolation_amd import synth
 lib = C.CDLL(os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "ab/libpass_ends.so"))
-B = 1_000_000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 d = synth.torch_batch(B, 64, 16)
 Kq, Tq = synth.query_grids(64, 16); Kq = torch.from_numpy(Kq).cuda(); Tq = torch.from_numpy(Tq).cuda()
 out = torch.empty((B, 16, 64), dtype=torch.float64, device="cuda"); st = torch.empty(B, dtype=torch.int32, device="cuda")
