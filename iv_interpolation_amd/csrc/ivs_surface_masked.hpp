@@ -335,10 +335,11 @@ inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
     int64_t grid = (int64_t)cx.num_cu * (lerp ? 12 : 8);
     const int64_t work = (p.B + 63) / 64;
     if (grid > work) grid = work;
-    if (IVS_MASKED_PASS && (p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) {
+    if (p.method == IVS_QUADRATIC || (IVS_MASKED_PASS && (p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE))) {
         int64_t g12 = (int64_t)cx.num_cu * 12;
         if (g12 > work) g12 = work;
         if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_CUBIC>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
+        else if (p.method == IVS_QUADRATIC) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_QUADRATIC>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
         else hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_CUBICSPLINE>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
         return true;
     }

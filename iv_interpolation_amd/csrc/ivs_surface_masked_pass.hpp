@@ -26,6 +26,9 @@ __host__ __device__ constexpr size_t masked_pass_lds_bytes() { return (size_t)(2
 
 // Not-a-knot slopes of the 8 compacted rows staged in (YC, XS): XS holds the compacted strikes on entry and the slopes on
 // exit.  All 64 lanes; the caller brackets it with barriers.  n = NROW[row] >= 4.
+// QUAD: the collocation system of the quadratic B-spline (quad_row, ivs_device.hpp) instead -- rows (lo, di, up), right-hand
+// side y_i, rows 0 and n - 1 the identity; the solution = the B-spline coefficients; n >= 3.
+template <bool QUAD = false>
 __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, const int* NROW, int lane) {
     const int r = lane >> 3, seg = lane & 7, i0 = seg * 8;
     const int n = NROW[r];
@@ -53,6 +56,11 @@ __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, cons
         const double rl = (dx1 * dx1 * dl0 + (2.0 * d + dx1) * dx0 * dl1) * rd;          // row n - 1
         a = first ? 0.0 : (last ? d : a); b = first ? dx3 : (last ? dx0 : b); c = first ? d : (last ? 0.0 : c);
         rr = first ? rf : (last ? rl : rr);
+        if (QUAD) {
+            const CView xv{xr, 1};
+            quad_row(xv, n, in ? i : 0, a, b, c);
+            rr = yr[in ? i : 0];
+        }
         a = in ? a : 0.0; b = in ? b : 1.0; c = in ? c : 0.0; rr = in ? rr : 0.0;
         const double rb = refined_rcp(b);
         u[k] = c * rb; l[k] = a * rb; rh[k] = rr * rb;
@@ -132,7 +140,9 @@ __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, cons
 
 template <int METHOD>
 __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParams p) {
-    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE, "not-a-knot methods only");
+    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE || METHOD == IVS_QUADRATIC, "tridiagonal methods only");
+    constexpr bool QUAD = METHOD == IVS_QUADRATIC;
+    constexpr int MINROW = QUAD ? 3 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParam
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             vm[t] = __ballot(!__builtin_isnan(v[t]));
-            give_up = give_up || __ballot(__builtin_isinf(v[t])) != 0ull || __popcll(vm[t]) < 4;
+            give_up = give_up || __ballot(__builtin_isinf(v[t])) != 0ull || __popcll(vm[t]) < MINROW;
         }
         if (give_up) { leave(); continue; }                    // wave-uniform; the sentinel stays
         __syncthreads();                                       // the previous surface's readers are done with LDS
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParam
 #pragma unroll
                 for (int st = 4; st >= 1; st >>= 1) if (Ksh[jf + st] <= xq) jf += st;
             }
-            masked_solve8(YC, XS, NROW, lane);
+            masked_solve8<QUAD>(YC, XS, NROW, lane);
             __syncthreads();
             // ---- strike evaluation of the pass's rows (q-lane): per row one RANK byte away from the full-grid interval
 #pragma unroll
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParam
                 const int j = jf >= 0 ? (int)RANK[r * DK + jf] - 1 : -1;
                 const MaskedX X{Ksh, IDX + r * DK};
                 const CView Y{YC + r * MK_RS, 1}, S{XS + r * MK_RS, 1};
-                const double zz = eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
+                const double zz = QUAD ? eval_quadratic(X, S, n, j, xq) : eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
                 z[ps * MP_ROWS + r] = zz;
                 all_ok = all_ok && !__builtin_isnan(zz);
             }

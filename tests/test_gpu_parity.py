@@ -979,8 +979,7 @@ def test_missing_quotes_first_mode(method):
     at least half of the sampled surfaces lack a quote the fast kernel returns at once and the compaction kernel takes EVERY
     surface ('missing quotes first').  Three batches against the oracle: (a) 10 % of all quotes missing (mode on), (b) quotes
     missing ONLY in the sampled surfaces (mode on, 99 % of the surfaces are complete and still go through the compaction
-    kernel), (c) quotes missing everywhere EXCEPT in the sampled surfaces (mode off: tag + redo as before).  'quadratic'
-    has no compaction kernel: the mode must stay off for it."""
+    kernel), (c) quotes missing everywhere EXCEPT in the sampled surfaces (mode off: tag + redo as before)."""
     from iv_interpolation_amd import synth
     import c_oracle
     B = 6000
