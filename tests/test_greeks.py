@@ -99,3 +99,17 @@ def test_preserve_greeks_epilogue_on_gpu_against_reference_golden(name):
     iv = IVInterpolator(method, 10, preserve_greeks=True)
     _check_greeks_frame(iv.interpolate_symbol(df), name)
     _check_greeks_frame(iv.interpolate_frame(df), name)
+
+
+def test_greeks_are_nan_when_a_channel_is_an_object_column():
+    """Series.interpolate leaves an object-dtype channel alone (reference core.py:61): the epilogue has no interpolated
+    value to work from and must report NaN, not numbers computed from placeholders."""
+    from oracle_backend import OracleBackend
+    from iv_interpolation_amd import IVInterpolator
+    name = str(gf["names"][0])
+    df = _gf_input(name)
+    df["underlying_price"] = df["underlying_price"].astype(object)
+    iv = IVInterpolator("linear", 10, backend=OracleBackend(), preserve_greeks=True)
+    for got in (iv.interpolate_symbol(df), iv.interpolate_frame(df)):
+        assert got is not None and len(got) > 0
+        assert all(got[c].isna().all() for c in GREEKS), got[GREEKS].head()
