@@ -987,7 +987,7 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
     // surfaces spread over the batch is sampled here; when at least half of them lack a quote the call runs
     // "missing quotes first": the fast kernel returns at once and the compaction kernel takes EVERY surface.
     int mode = 0;
-    if (!NTR && p.mK <= 64 && p.B >= 4096) {
+    if (!NTR && !p.k_off && p.nK == DK && p.mK <= 64 && p.B >= 4096) {
         int hit = 0;
 #pragma unroll 8
         for (int s = 0; s < 64; ++s) {

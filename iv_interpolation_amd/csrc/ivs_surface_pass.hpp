@@ -475,7 +475,9 @@ __device__ __forceinline__ void pass_local_slopes(const double* Yp, double* Sp, 
 __device__ unsigned long long* d_pass_ends = nullptr;
 #endif
 
-template <int METHOD, int NKB, bool VAR, int SL = 8, bool TSH = true>
+// NT16 (VAR only): the batch has the full 16 maturities (BASELINE config 5): the run-time maturity count -- masked rows, the
+// third tap of the last system row, the select chain for the hold row -- compiles away (~60 VALU instructions per surface).
+template <int METHOD, int NKB, bool VAR, int SL = 8, bool TSH = true, bool NT16 = false>
 // Wavefronts per SIMD: 3 (168 VGPRs); the run-time-shape instantiations of pchip / akima need ~200 (the per-lane maturity
 // solve of the local rules) and run at 2 without scratch -- at 3 they spilled 14-36 registers and lost 3-30 %.
 __global__ __launch_bounds__(64, SL == 4 ? 4 : ((d_is_local(METHOD) && VAR) ? 2 : 3))
@@ -520,7 +522,8 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
     const double* TTp = nullptr;
     const double* Wp = nullptr;
     if (TSH) tq_from_shared(p.tqs, tt, TTp, Wp);
-    const int nT = VAR ? p.nT : DT;
+    constexpr bool NTR = VAR && !NT16;               // run-time maturity count
+    const int nT = NTR ? p.nT : DT;
 
     // spare slots that are read but never staged must hold finite numbers (they meet zero coefficients)
     for (int i = lane; i < (LERP ? 1 : 2) * G::PLANE; i += 64) Yp[i] = 0.0;
@@ -615,7 +618,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
         if (!kq_shared) xq = act ? p.Kq[b * p.kq_stride + lane] : nanv;      // issued ahead of the next prefetch (vmcnt is in order)
         if (!TSH) {
             __syncthreads();                                   // the previous surface is done with the planes and with TT / W
-            dense_t_phase<METHOD, true, VAR>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, LERP ? Yp : Yp + 600, TTl, Wl, tt, nT, Yp);
+            dense_t_phase<METHOD, true, NTR>(p.T + b * p.t_stride, p.Tq + b * p.tq_stride, mT, lane, LERP ? Yp : Yp + 600, TTl, Wl, tt, nT, Yp);
             // the scratch may leave non-finite numbers in the rows' spare slots (they meet zero coefficients): clear them
             if (NKB == 1 && !LERP && lane < 2 * RP) { Yp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; Sp[(lane >> 1) * RS + KCAP + (lane & 1)] = 0.0; }
         }
@@ -776,7 +779,7 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
 #pragma unroll
                 for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
             }
-            if (act) dense_maturity_pass<METHOD, true, false, VAR, TSH>(z, tt, TSH ? TTp : TTl, TSH ? Wp : Wl, outb, 0, lane, true, mT, mK,
+            if (act) dense_maturity_pass<METHOD, true, false, NTR, TSH>(z, tt, TSH ? TTp : TTl, TSH ? Wp : Wl, outb, 0, lane, true, mT, mK,
                                                                         nostamp, 0, 0, nT);
             if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
         } else if (lane == 0) {
@@ -791,10 +794,18 @@ void surface_pass_kernel(SurfaceParams p, VarList list) {
 #endif
 }
 
+// one launch; run-time-shape batches with the full 16 maturities take the NT16 instantiation
+template <int METHOD, int NKB, bool VAR, int SL>
+inline void launch_pass_nt(bool nt16, int64_t grid, size_t lds, hipStream_t st, const SurfaceParams& p, const VarList& list) {
+    if constexpr (VAR) {
+        if (nt16) { hipLaunchKernelGGL((surface_pass_kernel<METHOD, NKB, true, SL, true, true>), dim3((unsigned)grid), dim3(64), lds, st, p, list); return; }
+    }
+    hipLaunchKernelGGL((surface_pass_kernel<METHOD, NKB, VAR, SL, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, list);
+}
 // akima exists on the run-time-shape kernels only (the 64 x 16 instantiation would spill at 168 VGPRs and is never built)
 template <int NKB, bool VAR>
-inline void launch_pass_akima(int64_t grid, size_t lds, hipStream_t st, const SurfaceParams& p, const VarList& list) {
-    if constexpr (VAR) hipLaunchKernelGGL((surface_pass_kernel<IVS_AKIMA, NKB, true, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, list);
+inline void launch_pass_akima(bool nt16, int64_t grid, size_t lds, hipStream_t st, const SurfaceParams& p, const VarList& list) {
+    if constexpr (VAR) launch_pass_nt<IVS_AKIMA, NKB, true, 8>(nt16, grid, lds, st, p, list);
 }
 
 // Dispatch of the row-pass kernels.  Returns 1 if dispatched (pass kernel(s) + filtered generic redo pass), 0 if the
@@ -812,10 +823,14 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     if (!p.k_off && p.k_stride != 0 && p.k_stride < p.nK) return 0;
     if (p.k_off && p.B > 0x7fffffffLL) return 0;
     const bool fixed64 = !p.k_off && p.nK == DK && p.nT == DT && !(reinterpret_cast<uintptr_t>(p.sigma) & 15);
+#ifndef IVS_PASS_NT16
+#define IVS_PASS_NT16 1      // 0: A/B builds without the NT16 instantiations
+#endif
+    const bool nt16 = IVS_PASS_NT16 && p.nT == DT;       // run-time-shape kernels: maturity count fixed at compile time (NT16)
     if (fixed64 && p.method == IVS_AKIMA) return 0;      // 64 x 16 akima: the one-pass kernel (256 VGPRs) wins -- at 168 it spills 50 registers
     TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
     if (tsh) {
-        if (fixed64) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);
+        if (fixed64 || nt16) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);      // 16 maturities: the fixed-count tables
         p.tqs = tq;
         p.redo = tq->redo;
         p.mode = fixed64 ? &tq->mode : nullptr;
@@ -870,16 +885,16 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
             hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, 8, false>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST);                              \
         } else                                                                                                                           \
         switch (p.method) {                                                                                                              \
-            case IVS_CUBIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBIC, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;             \
-            case IVS_CUBICSPLINE: hipLaunchKernelGGL((surface_pass_kernel<IVS_CUBICSPLINE, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
-            case IVS_LINEAR: hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;           \
-            case IVS_NEAREST: hipLaunchKernelGGL((surface_pass_kernel<IVS_NEAREST, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;         \
-            case IVS_ZERO: hipLaunchKernelGGL((surface_pass_kernel<IVS_ZERO, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
-            case IVS_FROM_DERIVATIVES: hipLaunchKernelGGL((surface_pass_kernel<IVS_FROM_DERIVATIVES, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break; \
-            case IVS_QUADRATIC: hipLaunchKernelGGL((surface_pass_kernel<IVS_QUADRATIC, NKB_, VAR_, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;       \
-            case IVS_PCHIP: hipLaunchKernelGGL((surface_pass_kernel<IVS_PCHIP, NKB_, VAR_, 8>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;               \
-            case IVS_AKIMA: launch_pass_akima<NKB_, VAR_>(grid, lds, st, p, LIST); break;                                                \
-            default: hipLaunchKernelGGL((surface_pass_kernel<IVS_SLINEAR, NKB_, VAR_, SL_>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST); break;                  \
+            case IVS_CUBIC: launch_pass_nt<IVS_CUBIC, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break;             \
+            case IVS_CUBICSPLINE: launch_pass_nt<IVS_CUBICSPLINE, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break; \
+            case IVS_LINEAR: launch_pass_nt<IVS_LINEAR, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break;           \
+            case IVS_NEAREST: launch_pass_nt<IVS_NEAREST, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break;         \
+            case IVS_ZERO: launch_pass_nt<IVS_ZERO, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break;               \
+            case IVS_FROM_DERIVATIVES: launch_pass_nt<IVS_FROM_DERIVATIVES, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break; \
+            case IVS_QUADRATIC: launch_pass_nt<IVS_QUADRATIC, NKB_, VAR_, 8>(nt16, grid, lds, st, p, LIST); break;       \
+            case IVS_PCHIP: launch_pass_nt<IVS_PCHIP, NKB_, VAR_, 8>(nt16, grid, lds, st, p, LIST); break;               \
+            case IVS_AKIMA: launch_pass_akima<NKB_, VAR_>(nt16, grid, lds, st, p, LIST); break;                                                \
+            default: launch_pass_nt<IVS_SLINEAR, NKB_, VAR_, SL_>(nt16, grid, lds, st, p, LIST); break;                  \
         }                                                                                                                                \
     }
 #endif
