@@ -475,12 +475,16 @@ __device__ __forceinline__ void pass_local_slopes(const double* Yp, double* Sp, 
 __device__ unsigned long long* d_pass_ends = nullptr;
 #endif
 
+#ifndef IVS_PCHIP3
+#define IVS_PCHIP3 3      // bit 0: pchip NT16 <= 64 strikes at 3 wavefronts per SIMD (161 VGPRs, no scratch); bit 1: 65..128 strikes too (48 B scratch)
+#endif
+__host__ __device__ constexpr bool pass_local_three(int method, int nkb, bool nt16) { return method == IVS_PCHIP && nt16 && ((IVS_PCHIP3 >> (nkb - 1)) & 1); }
 // NT16 (VAR only): the batch has the full 16 maturities (BASELINE config 5): the run-time maturity count -- masked rows, the
 // third tap of the last system row, the select chain for the hold row -- compiles away (~60 VALU instructions per surface).
 template <int METHOD, int NKB, bool VAR, int SL = 8, bool TSH = true, bool NT16 = false>
 // Wavefronts per SIMD: 3 (168 VGPRs); the run-time-shape instantiations of pchip / akima need ~200 (the per-lane maturity
 // solve of the local rules) and run at 2 without scratch -- at 3 they spilled 14-36 registers and lost 3-30 %.
-__global__ __launch_bounds__(64, SL == 4 ? 4 : ((d_is_local(METHOD) && VAR) ? 2 : 3))
+__global__ __launch_bounds__(64, SL == 4 ? 4 : ((d_is_local(METHOD) && VAR && !pass_local_three(METHOD, NKB, NT16)) ? 2 : 3))
 void surface_pass_kernel(SurfaceParams p, VarList list) {
 #ifdef IVS_PASS_ENDSTAMP
     if (threadIdx.x == 0 && d_pass_ends) d_pass_ends[blockIdx.x * 2] = wall_clock64();
@@ -879,7 +883,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
     {                                                                                                                                    \
         size_t lds = lerp ? pass_lds_bytes<NKB_, VAR_, SL_, 1>() : (local ? pass_lds_bytes<NKB_, VAR_, SL_, 2>() : pass_lds_bytes<NKB_, VAR_, SL_, 0>());  \
         if (!tsh) lds += PASS_TQ_DOUBLES * 8;                                                                                            \
-        const int64_t grid = grid_for(lds, p.B, (local && (VAR_)) ? 8 : (CAP));                                                          \
+        const int64_t grid = grid_for(lds, p.B, (local && (VAR_) && !pass_local_three(p.method, NKB_, nt16)) ? 8 : (CAP));               \
         if (!(VAR_)) p.map_groups = dense_map_groups(grid, p.B, cx.map_groups);                                                          \
         if (!tsh) {                                                                                                                      \
             hipLaunchKernelGGL((surface_pass_kernel<IVS_LINEAR, NKB_, VAR_, 8, false>), dim3((unsigned)grid), dim3(64), lds, st, p, LIST);                              \
