@@ -68,7 +68,7 @@ enum {
 enum {
     IVS_ST_OK            = 0,
     IVS_ST_TOO_FEW_KNOTS = 1, /* the reference's scipy call raises here -> interpolate_symbol returns None */
-    IVS_ST_BAD_SHAPE     = 2, /* ragged surface whose k_off span is negative or exceeds nK: skipped, outputs untouched */
+    IVS_ST_BAD_SHAPE     = 2, /* ragged surface whose k_off span is negative, exceeds nK or leaves the strike array: skipped, outputs untouched */
     IVS_ST_ILL_CONDITIONED = 4 /* 'barycentric' / 'krogh' with more than IVS_POLY_MAX_KNOTS valid knots: values are NaN */
 };
 
@@ -212,6 +212,9 @@ int ivs_frame_columns_f64(const ivs_frame_args* args /* host */, void* workspace
  *   Kq/Tq  query grids of surface b at Kq + b*kq_stride / Tq + b*tq_stride (0 = shared), mK / mT points
  *   out    [B][mT][mK]
  *   status [B] or NULL; IVS_ST_* OR-ed over every 1-D solve of the surface
+ *   NaN in sigma = missing quote: the row keeps its own knot set.  64 x 16 batches are probed by the call itself (row 0 of 64
+ *          surfaces spread over the batch): when most snapshots lack a quote every surface goes to the compaction kernel
+ *          directly, otherwise the fast kernel tags the few that do and a second pass redoes them -- no flag, same results
  *   flags  0, or IVS_FLAG_FORCE_GENERIC to bypass the dense fast path (testing / A-B timing); bits 8..15 =
  *          IVS_FLAG_MAP_GROUPS(n): tuning override of the surface -> workgroup mapping of the 64x16 kernel (0 = default)
  *   workspace  ivs_surface_workspace_bytes(B, ragged) bytes of device scratch (ragged = k_off != NULL): the
