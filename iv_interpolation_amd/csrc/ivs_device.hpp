@@ -290,12 +290,14 @@ template <class XA>
 __device__ __forceinline__ void quad_basis(const XA& x, int n, int ell, double xv, double& h0, double& h1, double& h2) {
     const double tm1 = quad_knot(x, n, ell - 1), t0 = quad_knot(x, n, ell), t1 = quad_knot(x, n, ell + 1),
                  t2 = quad_knot(x, n, ell + 2);
-    const double w = 1.0 / (t1 - t0);
+    // the three divisions of _deBoor_D as reciprocal (<= 1 ulp) times numerator: a third of the instructions of the IEEE
+    // division expansion, and this function runs per site AND per output value on the kernels whose rows have their own knots
+    const double w = refined_rcp(t1 - t0);
     const double a0 = w * (t1 - xv), a1 = w * (xv - t0);                      // order 1
-    const double w1 = a0 / (t1 - tm1);
+    const double w1 = a0 * refined_rcp(t1 - tm1);
     h0 = 0.0 + w1 * (t1 - xv);
     h1 = w1 * (xv - tm1);
-    const double w2 = a1 / (t2 - t0);
+    const double w2 = a1 * refined_rcp(t2 - t0);
     h1 += w2 * (t2 - xv);
     h2 = w2 * (xv - t0);
 }

@@ -45,25 +45,44 @@ __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, cons
     double xl = xe, yl = ye;                                       // last knot of the window
     double u[8], l[8], rh[8];                                      // normalised rows: upper, lower, right-hand side
     double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;             // product of the segment's Moebius matrices
+    // The two not-a-knot boundary rows are built ONCE, outside the loop over the segment (inside it they cost a reciprocal,
+    // two right-hand sides and eight selects per knot for two knots of a row): row 0 from the initial window of segment 0,
+    // row n - 1 from the row's last three knots; the loop takes them by one select per coefficient.
+    double uF = 0.0, lF = 0.0, rF = 0.0, uL = 0.0, lL = 0.0, rL = 0.0;
+    int kl = -1;                                                   // the lane's k of row n - 1 (or none)
+    if (!QUAD) {
+        {   // row 0: b = dx3, c = d, rhs = ((dx2 + 2 d) dx3 dl2 + dx2^2 dl3) / d with d = dx2 + dx3 (seg 0: xc = x_0)
+            const double d = dx2 + dx3, rb = refined_rcp(dx3);
+            uF = d * rb;
+            rF = ((dx2 + 2.0 * d) * dx3 * dl2 + dx2 * dx2 * dl3) * refined_rcp(d) * rb;
+        }
+        {   // row n - 1: a = d, b = dx0, rhs = (dx1^2 dl0 + (2 d + dx1) dx0 dl1) / d on the knots n-3, n-2, n-1
+            const double x3 = xr[n - 3], x2 = xr[n - 2], x1 = xr[n - 1], y3 = yr[n - 3], y2 = yr[n - 2], y1 = yr[n - 1];
+            const double e0 = x2 - x3, e1 = x1 - x2, g0 = (y2 - y3) * refined_rcp(e0), g1 = (y1 - y2) * refined_rcp(e1);
+            const double d = e0 + e1, rb = refined_rcp(e0);
+            lL = d * rb;
+            rL = (e1 * e1 * g0 + (2.0 * d + e1) * e0 * g1) * refined_rcp(d) * rb;
+            kl = ((n - 1) >> 3) == seg ? ((n - 1) & 7) : -1;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = i0 + k;
-        const bool in = i < n, first = k == 0 && i == 0, last = i == n - 1;      // (k > 0: `first` folds away with its formulas)
-        const double d = first ? dx2 + dx3 : dx0 + dx1;
-        const double rd = refined_rcp(d);
+        const bool in = i < n;
         double a = dx2, b = 2.0 * (dx1 + dx2), c = dx1, rr = 3.0 * (dx2 * dl1 + dx1 * dl2);
-        const double rf = ((dx2 + 2.0 * d) * dx3 * dl2 + dx2 * dx2 * dl3) * rd;          // row 0
-        const double rl = (dx1 * dx1 * dl0 + (2.0 * d + dx1) * dx0 * dl1) * rd;          // row n - 1
-        a = first ? 0.0 : (last ? d : a); b = first ? dx3 : (last ? dx0 : b); c = first ? d : (last ? 0.0 : c);
-        rr = first ? rf : (last ? rl : rr);
         if (QUAD) {
             const CView xv{xr, 1};
             quad_row(xv, n, in ? i : 0, a, b, c);
             rr = yr[in ? i : 0];
         }
-        a = in ? a : 0.0; b = in ? b : 1.0; c = in ? c : 0.0; rr = in ? rr : 0.0;
         const double rb = refined_rcp(b);
-        u[k] = c * rb; l[k] = a * rb; rh[k] = rr * rb;
+        double uu = c * rb, ll = a * rb, hh = rr * rb;
+        if (!QUAD) {
+            if (k == 0) { const bool first = seg == 0; uu = first ? uF : uu; ll = first ? lF : ll; hh = first ? rF : hh; }
+            const bool last = k == kl;
+            uu = last ? uL : uu; ll = last ? lL : ll; hh = last ? rL : hh;
+        }
+        u[k] = in ? uu : 0.0; l[k] = in ? ll : 0.0; rh[k] = in ? hh : 0.0;
         const double n00 = u[k] * m10, n01 = u[k] * m11, n10 = m10 - l[k] * m00, n11 = m11 - l[k] * m01;      // M <- [[0,u],[-l,1]] M
         m00 = n00; m01 = n01; m10 = n10; m11 = n11;
         if (k < 7) {                                               // slide the window: the interval (i+2, i+3) enters

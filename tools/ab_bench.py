@@ -15,6 +15,7 @@ ap.add_argument("--nk", type=int, default=64); ap.add_argument("--mk", type=int,
 ap.add_argument("--ragged", action="store_true", help="config 5: strike counts lo..hi per surface")
 ap.add_argument("--lo", type=int, default=8); ap.add_argument("--hi", type=int, default=128)
 ap.add_argument("--outs", type=int, default=1, help="time every library on this many separately allocated output buffers (placement sensitivity)")
+ap.add_argument("--nan-frac", type=float, default=0.0, help="this share of the quotes missing (NaN), as bench.py --nan-frac")
 ap.add_argument("--check", action="store_true", help="compare the outputs of the libraries (max abs diff vs the first)")
 a = ap.parse_args()
 _p, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
@@ -36,6 +37,9 @@ if a.ragged:
 else:
     d = synth.torch_batch(a.batch, a.nk, 16)
     koff, nk, kstr = None, a.nk, a.nk
+if a.nan_frac > 0:
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    d["sigma"][torch.rand(d["sigma"].shape, generator=g, device="cuda") < a.nan_frac] = float("nan")
 Kq, Tq = synth.query_grids(a.mk, a.mt); Kq = torch.from_numpy(Kq).cuda(); Tq = torch.from_numpy(Tq).cuda()
 out = torch.empty((a.batch, a.mt, a.mk), dtype=torch.float64, device="cuda"); st = torch.empty(a.batch, dtype=torch.int32, device="cuda")
 code = _lib.METHOD_CODES[a.method]
