@@ -15,6 +15,7 @@ a missing libivs.so or GPU raises ``EngineUnavailable`` (it is NOT turned into `
 """
 from __future__ import annotations
 
+import gc
 import logging
 from datetime import timedelta
 from typing import List, Optional, Sequence
@@ -55,6 +56,46 @@ def _chan_kind(col: pd.Series, fill_method: bool = False) -> str:
     if isinstance(dt, pd.api.extensions.ExtensionDtype):
         return "ext" if str(dt) in ("Float64", "Float32") else "f64"
     return "f32" if dt == np.float32 else "f64"
+
+
+def _concat_same_schema(frames, columns, dtypes) -> Optional[pd.DataFrame]:
+    """``pd.concat(frames, ignore_index=True)`` for frames that share columns, dtypes AND block layout -- the callers' usual
+    case: thousands of small frames cut from one query result -- or None when any frame differs (pd.concat decides then).
+    pd.concat spends ~50 us per frame planning the join (column union, per-block join units); here a frame costs one
+    look at its blocks, and every block position is one np.concatenate.  Reads the frames' block managers (the arrays
+    pandas itself holds); builds the result through the public constructor."""
+    try:
+        b0 = frames[0]._mgr.blocks
+        sig0 = [(b.dtype, b.mgr_locs.as_array.tobytes()) for b in b0]
+        if not all(isinstance(d, np.dtype) for d, _ in sig0):           # extension blocks (tz-aware dates, nullable floats)
+            return None
+        nb = len(b0)
+        parts = [[] for _ in range(nb)]
+        for f in frames:
+            bl = f._mgr.blocks
+            if len(bl) != nb:
+                return None
+            for k in range(nb):
+                b = bl[k]
+                if b.dtype != sig0[k][0] or b.mgr_locs.as_array.tobytes() != sig0[k][1]:
+                    return None
+                parts[k].append(b.values)
+        cols = [None] * len(columns)
+        for k in range(nb):
+            v0 = parts[k][0]
+            arrs = parts[k] if isinstance(v0, np.ndarray) else [np.asarray(v) for v in parts[k]]   # DatetimeArray -> M8[ns]
+            cat = np.concatenate(arrs, axis=1) if arrs[0].ndim == 2 else None
+            if cat is None or cat.dtype != sig0[k][0]:
+                return None
+            for r, ci in enumerate(b0[k].mgr_locs.as_array):
+                cols[int(ci)] = cat[r]
+        if any(c is None for c in cols):
+            return None
+        data = pd.DataFrame(dict(zip(range(len(cols)), cols)), copy=False)
+        data.columns = columns
+        return data if list(data.dtypes) == list(dtypes) else None
+    except (AttributeError, TypeError, ValueError):                       # another pandas: its own concat
+        return None
 
 
 def _objfill_source(cells: np.ndarray) -> np.ndarray:
@@ -277,7 +318,17 @@ class IVInterpolator:
 
     def interpolate_batch(self, frames: Sequence[pd.DataFrame]) -> List[Optional[pd.DataFrame]]:
         """Many symbols, one device round trip.  Element i is what interpolate_symbol(frames[i]) returns."""
-        fast = self._batch_via_frame(frames)
+        # The columnar path creates a few small long-lived pandas objects per symbol and no cyclic garbage; with the cyclic
+        # collector running, its passes over the caller's thousands of frames (and over the results made so far) are HALF
+        # of the call (2048 symbols: 0.24 s vs 0.13 s, tools/profile_batch.py).  Paused for the duration, state restored.
+        gc_was = gc.isenabled()
+        if gc_was:
+            gc.disable()
+        try:
+            fast = self._batch_via_frame(frames)
+        finally:
+            if gc_was:
+                gc.enable()
         if fast is not None:
             return fast
         preps: List[Optional[_Prepared]] = []
@@ -359,9 +410,13 @@ class IVInterpolator:
         lens = np.array([len(f) for f in frames], np.int64)
         if int(lens.sum()) == 0:
             return None
-        data = pd.concat(frames, ignore_index=True, copy=False)
-        if list(data.dtypes) != dt0 or any(list(f.dtypes) != dt0 for f in frames):      # one schema for all (dtype rules are per symbol)
-            return None
+        data = _concat_same_schema(frames, c0, dt0)                      # one schema for all (dtype rules are per symbol)
+        if data is None:
+            if any(list(f.dtypes) != dt0 for f in frames):
+                return None
+            data = pd.concat(frames, ignore_index=True, copy=False)
+            if list(data.dtypes) != dt0:
+                return None
         grp = np.repeat(np.arange(len(frames), dtype=np.int64), lens)
         be = self._backend or HipBackend()
         try:

@@ -22,7 +22,16 @@ namespace ivs {
 
 constexpr int FR_UNITS = 8;               // row pairs per thread
 constexpr int FR_ROWS = 256 * 2 * FR_UNITS;      // rows per block
-constexpr int FR_CAP = 256;               // staged source rows per block
+// Staged source rows per block (<= 256: one source row per thread).  The LDS image is 179 B per staged row; measured on the
+// reference's shape (tests/bench/bench_symbols.py, 64 hourly rows -> 3781 minute rows, a block touches 2-3 symbols = 128-192
+// source rows; profiles/r03/ab_frame_cap.txt): 256 rows = 48.9 KB = 3 blocks per CU 0.404 of HBM; 224 (3 per CU) 0.418;
+// 208 = 39.7 KB = 4 per CU **0.466**; 192 (4 per CU, rows of the column arrays 1536 B apart = the same banks again) 0.44;
+// 176 / 160 (4 / 5 per CU, but the three-symbol blocks fall to the window form) 0.394 / 0.409.
+#ifndef IVS_FR_CAP
+#define IVS_FR_CAP 208
+#endif
+constexpr int FR_CAP = IVS_FR_CAP;
+static_assert(FR_CAP <= 256 && FR_CAP % 16 == 0, "one staged source row per thread; 16-byte aligned column rows");
 constexpr int FR_MAXSYM = 64;             // symbols per block on the staged path
 constexpr int FR_MAXV = 16;               // validity rows (forward-filled columns + the three Greek inputs)
 constexpr int FR_MAXC = 3;                // channels
@@ -114,8 +123,8 @@ struct WinView {
 };
 
 struct FrameShared {
-    alignas(16) double cx[FR_MAXC][FR_CAP], cy[FR_MAXC][FR_CAP], cs[FR_MAXC][FR_CAP];     // 18 KB
-    alignas(16) double s_f[FR_MAXF][FR_CAP];                                               // 16 KB
+    alignas(16) double cx[FR_MAXC][FR_CAP], cy[FR_MAXC][FR_CAP], cs[FR_MAXC][FR_CAP];     // 14.6 KB
+    alignas(16) double s_f[FR_MAXF][FR_CAP];                                               // 13 KB
     int32_t s_c[FR_MAXCC][FR_CAP];                                                                         //  4 KB
     int32_t s_rel[FR_CAP];                 // output row of a staged source row, relative to the block's first row
     uint16_t s_rank[FR_MAXC][FR_CAP];      // valid knots of the channel among the symbol's rows 0..i
@@ -167,7 +176,7 @@ __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const I
     }
     if (tid == 0) { sh.y_qrel[nsym] = 0x7fffffff; sh.y_first[nsym] = 0x7fffffff; }
     __syncthreads();
-    {   // one staged source row per thread (NS <= FR_CAP = 256): every column load of the row is issued before the first
+    {   // one staged source row per thread (NS <= FR_CAP <= 256 = the block's threads): every column load of the row is issued before the first
         // LDS store waits for any of them (a load -> store loop with run-time trip counts serialised ~30 global round
         // trips per block: 45 of the block's 105 us in the first version of this kernel)
         const int i = tid;

@@ -163,3 +163,44 @@ def test_interpolate_batch_columnar_path_against_reference_goldens():
                 warnings.simplefilter("error")
                 g["batch_id"] = "b1"                             # batch_processor.py:105, complete_pipeline.py:323
     assert n_fast >= 8 and n_cases >= 120, (n_fast, n_cases)
+
+
+def test_same_schema_concat_equals_pd_concat_or_declines():
+    """interpolate_batch joins the callers' frames block by block (_concat_same_schema) when they share columns, dtypes and
+    block layout: must be pd.concat(frames, ignore_index=True) exactly -- or None, and pd.concat then decides."""
+    from iv_interpolation_amd.core import _concat_same_schema
+    from iv_interpolation_amd.frame_store import synthetic_symbol
+    frames = [synthetic_symbol(f"s{i}", 12 + i, seed=i) for i in range(9)]
+    frames.append(frames[0].iloc[2:7])                                   # a slice: non-owning 2-D block views
+    frames.append(frames[1].iloc[0:0])                                   # an empty frame
+    f0 = frames[0]
+    got = _concat_same_schema(frames, f0.columns, list(f0.dtypes))
+    assert got is not None
+    pd.testing.assert_frame_equal(got, pd.concat(frames, ignore_index=True))
+    g = frames[5].copy(); g["volume"] = g["volume"].fillna(0).astype("int64")          # another dtype in one frame
+    assert _concat_same_schema(frames[:5] + [g], f0.columns, list(f0.dtypes)) is None
+    h = frames[3].copy(); h["extra"] = 1.0; h = h.drop(columns="extra")                # same columns, may differ in block layout
+    r = _concat_same_schema(frames[:3] + [h], f0.columns, list(f0.dtypes))
+    if r is not None:
+        pd.testing.assert_frame_equal(r, pd.concat(frames[:3] + [h], ignore_index=True))
+    tz = [f.assign(date=f["date"].dt.tz_localize("UTC")) for f in frames[:4]]          # extension block: declined
+    assert _concat_same_schema(tz, tz[0].columns, list(tz[0].dtypes)) is None
+    iv = IVInterpolator("linear", backend=OracleBackend())
+    res = iv.interpolate_batch(tz + tz)                                  # ... and the batch call still answers through pd.concat
+    assert all(r is not None and str(r["date"].dtype) == "datetime64[ns, UTC]" for r in res)
+
+
+def test_batch_call_restores_the_collector_state():
+    import gc
+    from iv_interpolation_amd.frame_store import synthetic_symbol
+    frames = [synthetic_symbol(f"s{i}", 12, seed=i) for i in range(5)]
+    iv = IVInterpolator("linear", backend=OracleBackend())
+    assert gc.isenabled()
+    iv.interpolate_batch(frames)
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        iv.interpolate_batch(frames)
+        assert not gc.isenabled()                                        # a caller that had it off keeps it off
+    finally:
+        gc.enable()
