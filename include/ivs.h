@@ -293,6 +293,9 @@ const char* ivs_last_kernel(void);
  */
 int     ivs_debug_stamps(void* device_buf, int64_t n_u64);
 int64_t ivs_debug_last_grid(void);   /* workgroups of the last dense launch */
+/* byte offset, in the workspace a 64 x 16 surface call was given, of the int32 'missing quotes first' flag that call's
+ * probe left there (1 = the compaction kernel took every surface); tests read it back after the call */
+int64_t ivs_debug_mode_offset(void);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,7 @@ SIGNATURES = {
                                          _p, C.c_size_t, _p]),
     "ivs_debug_stamps": (C.c_int, [_p, _i64]),
     "ivs_debug_last_grid": (_i64, []),
+    "ivs_debug_mode_offset": (_i64, []),
     "ivs_surface_workspace_bytes": (_sz, [_i64, _i32]),
     "ivs_surface_batch_f64": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i32,
                                         _p, _p, _i32, _i32, _p, _sz, _p]),

@@ -75,6 +75,7 @@ int ivs_debug_stamps(void* device_buf, int64_t n_u64) {
 }
 
 int64_t ivs_debug_last_grid(void) { return g_last_grid; }
+int64_t ivs_debug_mode_offset(void) { return (int64_t)offsetof(ivs::TqShared, mode); }
 
 int ivs_device_count(void) {
     int n = 0;

@@ -981,20 +981,27 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
         o->CP[lane] = TT[lane * 4 + 3]; o->PP[lane] = TT[lane * 4]; o->QQ[lane] = TT[lane * 4 + 1]; o->AL[lane] = TT[lane * 4 + 2];
     }
     if (lane < p.mT) { o->W[lane * 4] = tt.w0; o->W[lane * 4 + 1] = tt.w1; o->W[lane * 4 + 2] = tt.w2; o->W[lane * 4 + 3] = tt.w3; }
-    // Missing-quote probe (64 x 16 batches only).  A surface with a missing quote is tagged by the fast kernel AFTER it has
-    // streamed all of its quotes, and the compaction kernel reads them again: with a feed in which (nearly) every snapshot
-    // lacks some quote that first pass is pure traffic (1.6 of 9.3 ms per 1 M surfaces at 10 % missing).  Row 0 of 64
-    // surfaces spread over the batch is sampled here; when at least half of them lack a quote the call runs
-    // "missing quotes first": the fast kernel returns at once and the compaction kernel takes EVERY surface.
+    // Missing-quote probe (64 x 16 batches only).  A surface with a missing quote is tagged by the fast kernel after it has
+    // streamed its quotes, and the compaction kernel reads them again: with a feed in which most snapshots lack some quote
+    // that first pass is pure traffic (1.5 ms per 1 M surfaces).  One row (row s mod 16) of 64 surfaces spread over the batch is
+    // sampled here, 4096 quotes; the call runs "missing quotes first" -- the fast kernel returns at once, the compaction
+    // kernel takes EVERY surface -- when
+    //   * at least half of the sampled rows lack a quote, or
+    //   * at least 5 of them do and they lack about one quote each (total <= 1.5 per such row): quotes missing here and
+    //     there, independently -- then 5 of 64 rows means >= 0.12 % of the quotes and, 1024 quotes per surface, >= 72 % of
+    //     the surfaces: the break-even of the two orders (3.0 + 5.4 a ms against 6.9 ms for a share a of tagged surfaces;
+    //     profiles/r03/nan/sparse_probe_rule.txt).  Several quotes missing per sampled row says the gaps cluster (illiquid strikes
+    //     of SOME snapshots): the share of surfaces hit is then about the share of rows hit, and tagging stays cheaper.
     int mode = 0;
     if (!NTR && !p.k_off && p.nK == DK && p.mK <= 64 && p.B >= 4096) {
-        int hit = 0;
+        int hit = 0, tot = 0;
 #pragma unroll 8
         for (int s = 0; s < 64; ++s) {
             const int64_t b = (int64_t)s * (p.B / 64);
-            hit += __ballot(__builtin_isnan(p.sigma[b * (int64_t)(DT * DK) + lane])) != 0ull ? 1 : 0;
+            const int c = __popcll(__ballot(__builtin_isnan(p.sigma[b * (int64_t)(DT * DK) + (s & (DT - 1)) * DK + lane])));
+            hit += c != 0 ? 1 : 0; tot += c;
         }
-        mode = hit >= 32 ? 1 : 0;
+        mode = (hit >= 32 || (hit >= 5 && 2 * tot <= 3 * hit)) ? 1 : 0;
     }
     if (lane == 0) {
         o->pm_last = tt.pm_last; o->iv_lo = tt.iv_lo; o->iv_hi = tt.iv_hi;
