@@ -290,6 +290,9 @@ __device__ __forceinline__ double pchip_edge(double m0, double m1, double ea, do
     return (d * m0 > 0.0) ? r : 0.0;                       // branch-free on purpose (selects)
 }
 // akima (scipy _cubic.py:510-541): secants ma..md = m_{i-2}, m_{i-1}, m_i, m_{i+1}
+#ifndef IVS_AKIMA_ROLL
+#define IVS_AKIMA_ROLL 1      // akima's maturity slopes formed while the output rows are walked (dense_maturity_pass)
+#endif
 __device__ __forceinline__ double akima_f12(double ma, double mb, double mc, double md) {
     return __builtin_fabs(md - mc) + __builtin_fabs(mb - ma);
 }
@@ -717,7 +720,8 @@ __device__ __forceinline__ void dense_t_phase(const double* Tb, const double* Tq
 // NTR: run-time maturity count nT_rt (see dense_t_phase): masked system rows, three-tap last row, hold row = nT_rt - 1.
 // SM: TT and W point at the TqShared tables in global memory; every read of them is a scalar load (uniform index),
 // the next row's weights are requested while the current row is combined and stored.
-template <int METHOD, bool WLDS, bool RANGED = false, bool NTR = false, bool SM = false, class StampFn>
+// AKROLL: akima's slopes formed while the rows are walked (see there); false where the registers are not the limit.
+template <int METHOD, bool WLDS, bool RANGED = false, bool NTR = false, bool SM = false, bool AKROLL = true, class StampFn>
 __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const TqTables& tt, const double* TT,
                                                     const double* W, double* outb, int q0, int lane, bool act, int mT,
                                                     int mK, StampFn&& stamp, int row_lo = 0, int row_hi = 0,
@@ -803,7 +807,60 @@ __device__ __forceinline__ void dense_maturity_pass(const double (&z)[DT], const
             a2 = readlane_f64(tt.w2, row); a3 = readlane_f64(tt.w3, row);
         }
     };
-    if (CUB) {
+    if (METHOD == IVS_AKIMA && IVS_AKIMA_ROLL && AKROLL) {
+        // akima, slopes formed WHILE the rows are walked: knot j needs the secants m_{j-2} .. m_{j+1} only, so a window of
+        // four secants slides along the 16 knots twice -- once for the row maximum of |m_{j+1} - m_j| + |m_{j-1} - m_{j-2}|
+        // (the threshold of the equal-secants rule), once in the row loop, where an interval needs just its two end slopes.
+        // Live: z[16], the window, two slopes -- not s[16] and the 19 secants a common-subexpression pass keeps between the
+        // two loops of dense_maturity_slopes_local (240 VGPRs on the run-time-shape kernels, 2 wavefronts per SIMD).  Same
+        // expressions in the same order: bit-identical.
+        double zz[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i) zz[i] = z[i];
+        auto secz = [&](int i) -> double {                     // m_i, i = 0..14 (run-time nT: the table is 0 from interval nT-1 on)
+            const double r0 = SM ? (double)cTT[i * 4] : TT[i * 4];
+            return (zz[i + 1] - zz[i]) * r0;
+        };
+        auto m_next = [&](int idx, double mb_, double mc_) -> double {      // m_idx, idx >= 2, from the two before it
+            const double raw = idx <= DT - 2 ? secz(idx < DT - 1 ? idx : DT - 2) : 0.0;
+            return (idx == nT - 1 || idx == nT) ? 2.0 * mc_ - mb_ : raw;     // linear extension behind the last knot
+        };
+        double thr;
+        {
+            const double m0 = secz(0), m1 = secz(1);
+            const double l1 = 2.0 * m0 - m1, l0 = 2.0 * l1 - m0;
+            double ma = l0, mb = l1, mc = m0, md = m1, fmax = 0.0;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const double f = akima_f12(ma, mb, mc, md);
+                fmax = (!NTR || i < nT) ? __builtin_fmax(fmax, f) : fmax;
+                const double nd = m_next(i + 2, mc, md);
+                ma = mb; mb = mc; mc = md; md = nd;
+            }
+            thr = 1e-9 * fmax;
+        }
+#pragma unroll
+        for (int i = 0; i < DT; ++i) asm volatile("" : "+v"(zz[i]));      // the second walk recomputes its secants
+        stamp(4);
+        const double m0 = secz(0), m1 = secz(1);
+        const double l1 = 2.0 * m0 - m1, l0 = 2.0 * l1 - m0;
+        double ma = l0, mb = l1, mc = m0, md = m1;
+        double s_lo = akima_knot(ma, mb, mc, md, thr);
+        { const double nd = m_next(2, mc, md); ma = mb; mb = mc; mc = md; md = nd; }
+#pragma unroll
+        for (int jv = 0; jv < DT - 1; ++jv) {
+            const double s_hi = akima_knot(ma, mb, mc, md, thr);          // knot jv + 1
+            { const double nd = m_next(jv + 3, mc, md); ma = mb; mb = mc; mc = md; md = nd; }
+            for (int c = 0, n = n_iv(jv); c < n; ++c, adv()) {
+                if (!mine(tq)) continue;
+                double a0, a1, a2, a3;
+                weights(tq, a0, a1, a2, a3);
+                put(tq, a0 * zz[jv] + a1 * zz[jv + 1] + a2 * s_lo + a3 * s_hi);
+            }
+            s_lo = s_hi;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (CUB) {
         double s[DT];
         double prev = 0.0;
         const double pm_last = NTR ? readlane_f64(tt.pm_last, 0) : 0.0;      // uniform -> SGPRs

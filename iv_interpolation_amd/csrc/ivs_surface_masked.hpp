@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
 #pragma unroll
             for (int r = 0; r < DT; ++r) asm volatile("" : "+v"(z[r]));      // see dense_maturity_pass
         }
-        if (act && all_ok) dense_maturity_pass<METHOD, true, false, false, true>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp);
+        if (act && all_ok) dense_maturity_pass<METHOD, true, false, false, true, false>(z, tt, TTp, Wp, outb, 0, lane, true, mT, mK, nostamp);      // 8 wavefronts per CU by LDS: akima keeps its slopes in registers (-2 % with the rolling form)
         if (p.status && lane == 0) p.status[b] = IVS_ST_OK;
       }
     }

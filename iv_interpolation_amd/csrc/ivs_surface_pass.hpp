@@ -427,8 +427,10 @@ __device__ __forceinline__ void pass_local_slopes(const double* Yp, double* Sp, 
         }
         fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));      // the row's 8 (16) segments: aligned lane groups
         fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
-        fmax = __builtin_fmax(fmax, __shfl_xor(fmax, 4));
-        if (NSEG > 8) fmax = __builtin_fmax(fmax, __shfl_xor(fmax, 8));
+        // the other quad of the 8-lane group / the other half of the 16-lane row: every lane of a quad (half) holds the same
+        // value by now, so the mirrored lane serves -- DPP moves instead of two ds_bpermute round trips per pass
+        fmax = __builtin_fmax(fmax, dpp_f64<0x141>(fmax, fmax));               // row_half_mirror: lane i <- lane 7 - i (of its 8)
+        if (NSEG > 8) fmax = __builtin_fmax(fmax, dpp_f64<0x140>(fmax, fmax)); // row_mirror: lane i <- lane 15 - i (of its 16)
         thr = 1e-9 * fmax;
     }
     // pchip: one-sided rule at the last knot n-1, wherever it falls: computed once from LDS, selected in below
@@ -478,7 +480,12 @@ __device__ unsigned long long* d_pass_ends = nullptr;
 #ifndef IVS_PCHIP3
 #define IVS_PCHIP3 3      // bit 0: pchip NT16 <= 64 strikes at 3 wavefronts per SIMD (161 VGPRs, no scratch); bit 1: 65..128 strikes too (48 B scratch)
 #endif
-__host__ __device__ constexpr bool pass_local_three(int method, int nkb, bool nt16) { return method == IVS_PCHIP && nt16 && ((IVS_PCHIP3 >> (nkb - 1)) & 1); }
+#ifndef IVS_AKIMA3
+#define IVS_AKIMA3 3      // the same for akima (164 / 166 VGPRs with the rolling maturity slopes, IVS_AKIMA_ROLL; 240 before)
+#endif
+__host__ __device__ constexpr bool pass_local_three(int method, int nkb, bool nt16) {
+    return nt16 && ((method == IVS_PCHIP && ((IVS_PCHIP3 >> (nkb - 1)) & 1)) || (method == IVS_AKIMA && ((IVS_AKIMA3 >> (nkb - 1)) & 1)));
+}
 // NT16 (VAR only): the batch has the full 16 maturities (BASELINE config 5): the run-time maturity count -- masked rows, the
 // third tap of the last system row, the select chain for the hold row -- compiles away (~60 VALU instructions per surface).
 template <int METHOD, int NKB, bool VAR, int SL = 8, bool TSH = true, bool NT16 = false>
@@ -806,10 +813,12 @@ inline void launch_pass_nt(bool nt16, int64_t grid, size_t lds, hipStream_t st, 
     }
     hipLaunchKernelGGL((surface_pass_kernel<METHOD, NKB, VAR, SL, true, false>), dim3((unsigned)grid), dim3(64), lds, st, p, list);
 }
-// akima exists on the run-time-shape kernels only (the 64 x 16 instantiation would spill at 168 VGPRs and is never built)
+#ifndef IVS_AKIMA_FIXED
+#define IVS_AKIMA_FIXED 1      // 64 x 16 akima on the row-pass kernel (0: the one-pass kernel, rounds 1-2)
+#endif
 template <int NKB, bool VAR>
 inline void launch_pass_akima(bool nt16, int64_t grid, size_t lds, hipStream_t st, const SurfaceParams& p, const VarList& list) {
-    if constexpr (VAR) launch_pass_nt<IVS_AKIMA, NKB, true, 8>(nt16, grid, lds, st, p, list);
+    if constexpr (VAR || (IVS_AKIMA_FIXED && NKB == 1)) launch_pass_nt<IVS_AKIMA, NKB, VAR, 8>(nt16, grid, lds, st, p, list);
 }
 
 // Dispatch of the row-pass kernels.  Returns 1 if dispatched (pass kernel(s) + filtered generic redo pass), 0 if the
@@ -831,7 +840,7 @@ inline int launch_surface_pass(const SurfaceParams& p_in, const LaunchCtx& cx, c
 #define IVS_PASS_NT16 1      // 0: A/B builds without the NT16 instantiations
 #endif
     const bool nt16 = IVS_PASS_NT16 && p.nT == DT;       // run-time-shape kernels: maturity count fixed at compile time (NT16)
-    if (fixed64 && p.method == IVS_AKIMA) return 0;      // 64 x 16 akima: the one-pass kernel (256 VGPRs) wins -- at 168 it spills 50 registers
+    if (!IVS_AKIMA_FIXED && fixed64 && p.method == IVS_AKIMA) return 0;      // rounds 1-2: 64 x 16 akima stayed on the one-pass kernel (at 168 VGPRs the row-pass form spilled 50 registers; see IVS_AKIMA_ROLL)
     TqShared* tq = reinterpret_cast<TqShared*>(cx.ws);
     if (tsh) {
         if (fixed64 || nt16) launch_tq_tables<false>(p, tq, st); else launch_tq_tables<true>(p, tq, st);      // 16 maturities: the fixed-count tables
