@@ -25,6 +25,9 @@ for m in cubic cubicspline linear pchip akima quadratic nearest; do      # 10 % 
   python bench.py --steps 5 --warmup 2 --method $m --nan-frac 0.1 --no-cpu-baseline --no-other-configs > $O/bench_cfg3_${m}_nan10.json 2> $O/bench_nan10_$m.err || { tail -5 $O/bench_nan10_$m.err; exit 1; }
 done
 python bench.py --steps 5 --warmup 2 --method cubic --nan-frac 0.0005 --no-cpu-baseline --no-other-configs > $O/bench_cfg3_cubic_nan_few.json 2> $O/bench_nan_few.err || exit 1
+for m in cubic linear; do      # 0.5 % missing: the sparse rule of the probe
+  python bench.py --steps 5 --warmup 2 --method $m --nan-frac 0.005 --no-cpu-baseline --no-other-configs > $O/bench_cfg3_${m}_nan05.json 2>> $O/bench_nan_few.err || exit 1
+done
 for b in 125000 250000 500000; do      # the cfg3 / cfg5 shards of the 8-, 4- and 2-GPU split
   python bench.py --batch $b --no-other-configs --no-cpu-baseline > $O/bench_cfg3_cubic_b$b.json 2>> $O/bench_small.err || exit 1
   python bench.py --workload cfg5 --batch $b --no-other-configs --no-cpu-baseline > $O/bench_cfg5_cubic_b$b.json 2>> $O/bench_small.err || exit 1
@@ -55,7 +58,8 @@ if [ "$PART" = "part3" ]; then
 bash tools/pmc_run.sh cubic --steps 5 --warmup 1 --no-other-configs > $O/pmc_cubic.txt 2>&1 || { tail -5 $O/pmc_cubic.txt; exit 1; }
 bash tools/pmc_run.sh cfg5 --steps 3 --warmup 1 --workload cfg5 > $O/pmc_cfg5.txt 2>&1 || { tail -5 $O/pmc_cfg5.txt; exit 1; }
 bash tools/pmc_run.sh nan10 --steps 3 --warmup 1 --nan-frac 0.1 --no-other-configs > $O/pmc_nan10.txt 2>&1 || { tail -5 $O/pmc_nan10.txt; exit 1; }
-for t in cubic cfg5 nan10; do cp $R/gpurun_out/pmc_$t/summary.json $O/pmc_$t.json; done
+PMC_PROG="tests/bench/bench_symbols.py --device-only" bash tools/pmc_run.sh symbols --method linear > $O/pmc_symbols.txt 2>&1 || { tail -5 $O/pmc_symbols.txt; exit 1; }
+for t in cubic cfg5 nan10 symbols; do cp $R/gpurun_out/pmc_$t/summary.json $O/pmc_$t.json; done
 fi
 python - <<'PY'
 import json,glob,os
