@@ -280,7 +280,11 @@ __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const I
             jr[u] = (j >= 0 && (int)sh.s_symk[j] == k) ? j : -1;
         }
         // ---- channels (core.py:58-61): the merged column = the interpolant, knot rows keep their source cell
-        double gv[3][2] = {{nanv, nanv}, {nanv, nanv}, {nanv, nanv}};
+        // the channel values the Greeks epilogue picks from, as SCALARS: as an array they were turned into a scratch array by
+        // the compiler (its select chain over a uniform channel number became a dynamically indexed load), 96 B of scratch
+        // stores per row pair whether Greeks were asked for or not -- 0.5 GB of HBM writes per 15 M rows by the counters
+        // (and so was a select chain over six scalars at the point of use: the choice is made where the value is produced)
+        double gS0 = nanv, gS1 = nanv, gT0 = nanv, gT1 = nanv, gI0 = nanv, gI1 = nanv;      // underlying, maturity, iv of the two rows
         bool row_ok[2] = {true, true};
 #pragma unroll
         for (int c = 0; c < FR_MAXC; ++c) {
@@ -316,8 +320,12 @@ __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const I
                     }
                 }
                 r2[u] = r;
-                gv[c][u] = r;
                 row_ok[u] = row_ok[u] && !__builtin_isnan(r) && !((sh.y_bad[kk] >> c) & 1);
+            }
+            if (f.greeks) {                                          // uniform selects, c is a constant of the unrolled loop
+                gS0 = c == f.ch_S ? r2[0] : gS0; gS1 = c == f.ch_S ? r2[1] : gS1;
+                gT0 = c == f.ch_T ? r2[0] : gT0; gT1 = c == f.ch_T ? r2[1] : gT1;
+                gI0 = c == f.ch_iv ? r2[0] : gI0; gI1 = c == f.ch_iv ? r2[1] : gI1;
             }
             double* o = p.out + (int64_t)c * p.out_stride + g;
             if (two) { v2d_u8 a; a.x = r2[0]; a.y = r2[1]; *reinterpret_cast<v2d_u8*>(o) = a; } else o[0] = r2[0];
@@ -382,8 +390,7 @@ __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const I
                 if (f.g_rate >= 0) { const int i = fill_index(f.g_rate, u); rate = i != NONE ? f.rate_src[W0 + i] : nanv; }
                 if (f.g_put >= 0) { const int i = fill_index(f.g_put, u); put = i != NONE ? f.put_src[W0 + i] : 2; }
                 double de, ga, th, ve, rh;
-                auto pick = [&](int ch) { return ch == 0 ? gv[0][u] : (ch == 1 ? gv[1][u] : gv[2][u]); };      // no dynamic register index
-                bs_greeks_one(pick(f.ch_S), K, pick(f.ch_T), rate, pick(f.ch_iv), put == 1, de, ga, th, ve, rh);
+                bs_greeks_one(u ? gS1 : gS0, K, u ? gT1 : gT0, rate, u ? gI1 : gI0, put == 1, de, ga, th, ve, rh);
                 if (put == 2) { de = nanv; ga = nanv; th = nanv; ve = nanv; rh = nanv; }
                 const int64_t gg = g + u;
                 f.greeks[0 * f.greeks_stride + gg] = de; f.greeks[1 * f.greeks_stride + gg] = ga;

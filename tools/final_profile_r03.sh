@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/final_profile_r03.sh [part1|part2|part3]   (gpurun calls of <= 20 min each)
+# usage: tools/final_profile_r03.sh [part1|part2|part3|part4]   (gpurun calls of <= 20 min each)
 # Round-3 measurement set on the GPU box -> gpurun_out/final/ (copied to profiles/r03/final/).
 #   part1: GPU tests, CLI pipeline, bench lines (first-allocation numbers: --placement-tries 1 is the default now)
 #   part2: rocprofv3 kernel traces of the same commands (rocprof avg must agree with the bench line), symbols / bridge benches
@@ -53,6 +53,17 @@ for s in spread_simulation price_as_midpoint simple_spread pipeline_inline trend
 python tools/ragged_probe.py > $O/ragged_probe.txt 2>&1 || exit 1
 python tools/layout_probe.py > $O/layout_probe.txt 2>&1 || exit 1
 rm -rf $O/trace_*/
+fi
+if [ "$PART" = "part4" ]; then      # the frame pass only (after a change to ivs_frame.hpp): traces, bench, counters
+cd /tmp && export TMPDIR=/tmp
+for m in linear cubic; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_symbols_$m -- python3 $R/tests/bench/bench_symbols.py --method $m --e2e 8 > /dev/null 2> $O/trace_symbols_$m.err || { tail -5 $O/trace_symbols_$m.err; exit 1; }
+  cp "$(find $O/trace_symbols_$m -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_symbols_$m.csv
+  python3 $R/tests/bench/bench_symbols.py --method $m > $O/bench_symbols_$m.json 2>> $O/bench_symbols.err || { tail -5 $O/bench_symbols.err; exit 1; }
+done
+cd $R; rm -rf $O/trace_*/
+PMC_PROG="tests/bench/bench_symbols.py --device-only" bash tools/pmc_run.sh symbols --method linear > $O/pmc_symbols.txt 2>&1 || { tail -5 $O/pmc_symbols.txt; exit 1; }
+cp $R/gpurun_out/pmc_symbols/summary.json $O/pmc_symbols.json
 fi
 if [ "$PART" = "part3" ]; then
 bash tools/pmc_run.sh cubic --steps 5 --warmup 1 --no-other-configs > $O/pmc_cubic.txt 2>&1 || { tail -5 $O/pmc_cubic.txt; exit 1; }
