@@ -1052,10 +1052,12 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
     int mode = 0;
     if (!NTR && !p.k_off && p.nK == DK && p.mK <= 64 && p.B >= 4096) {
         int hit = 0, tot = 0;
-#pragma unroll 8
+        double q[64];                                      // all 64 requests in flight before the first is looked at
+#pragma unroll
+        for (int s = 0; s < 64; ++s) q[s] = p.sigma[(int64_t)s * (p.B / 64) * (int64_t)(DT * DK) + (s & (DT - 1)) * DK + lane];
+#pragma unroll
         for (int s = 0; s < 64; ++s) {
-            const int64_t b = (int64_t)s * (p.B / 64);
-            const int c = __popcll(__ballot(__builtin_isnan(p.sigma[b * (int64_t)(DT * DK) + (s & (DT - 1)) * DK + lane])));
+            const int c = __popcll(__ballot(__builtin_isnan(q[s])));
             hit += c != 0 ? 1 : 0; tot += c;
         }
         mode = (hit >= 32 || (hit >= 5 && 2 * tot <= 3 * hit)) ? 1 : 0;
