@@ -212,8 +212,9 @@ int ivs_frame_columns_f64(const ivs_frame_args* args /* host */, void* workspace
  *   Kq/Tq  query grids of surface b at Kq + b*kq_stride / Tq + b*tq_stride (0 = shared), mK / mT points
  *   out    [B][mT][mK]
  *   status [B] or NULL; IVS_ST_* OR-ed over every 1-D solve of the surface
- *   NaN in sigma = missing quote: the row keeps its own knot set.  64 x 16 batches are probed by the call itself (row 0 of 64
- *          surfaces spread over the batch): when most snapshots lack a quote every surface goes to the compaction kernel
+ *   NaN in sigma = missing quote: the row keeps its own knot set.  64 x 16 batches are probed by the call itself (one row of
+ *          64 surfaces spread over the batch): when half of the sampled rows lack a quote -- or at least 5 of them lack about
+ *          one quote each: sparse independent gaps, which hit most SURFACES -- every surface goes to the compaction kernel
  *          directly, otherwise the fast kernel tags the few that do and a second pass redoes them -- no flag, same results
  *   flags  0, or IVS_FLAG_FORCE_GENERIC to bypass the dense fast path (testing / A-B timing); bits 8..15 =
  *          IVS_FLAG_MAP_GROUPS(n): tuning override of the surface -> workgroup mapping of the 64x16 kernel (0 = default)
