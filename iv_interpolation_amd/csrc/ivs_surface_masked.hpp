@@ -45,10 +45,14 @@ constexpr int MK_MAXCOL = 8;                      // masked output columns handl
 // accessors of a compacted row for eval_cubic
 struct MaskedX { const double* Ksh; const uint8_t* idx; __device__ __forceinline__ double operator()(int i) const { return Ksh[idx[i]]; } };
 
+// maximum over the wavefront: DPP inside the rows of 16 (quad swaps, half mirror, mirror), one scalar read per row across
+// them -- the six ds_bpermute round trips of a shuffle butterfly were a dependent LDS chain per ROW of an akima surface
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = __builtin_fmax(v, __shfl_xor(v, s));
-    return v;
+    v = __builtin_fmax(v, dpp_f64<DPP_QUAD_SWAP1>(v, v));
+    v = __builtin_fmax(v, dpp_f64<DPP_QUAD_SWAP2>(v, v));
+    v = __builtin_fmax(v, dpp_f64<0x141>(v, v));               // row_half_mirror
+    v = __builtin_fmax(v, dpp_f64<0x140>(v, v));               // row_mirror: every lane holds its row's maximum
+    return __builtin_fmax(__builtin_fmax(readlane_f64(v, 0), readlane_f64(v, 16)), __builtin_fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 template <int METHOD>
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
                 }
                 z[t] = r;
             } else if (STEP) z[t] = eval_method(METHOD, X, Y, S, n, j, xq);
-            else if (LERP) z[t] = eval_linear(X, Y, n, j, xq, METHOD == IVS_LINEAR);
+            else if (LERP) z[t] = eval_linear(X, Y, n, j, xq, METHOD == IVS_LINEAR);      // (np.interp's division through div_shared_rcp: measured -5 % here -- the per-row range checks cost more than the 16 divisions)
             else z[t] = eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
             all_ok = all_ok && !__builtin_isnan(z[t]);
         }
