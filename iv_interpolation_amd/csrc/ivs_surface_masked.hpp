@@ -170,7 +170,8 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
                     if (n == 2) sk = readlane_f64(mc, 0);
                 } else {      // akima: secants extended linearly two steps beyond either end (scipy _cubic.py:520-528)
                     const double m0 = readlane_f64(mc, 0), m1 = readlane_f64(mc, 1);
-                    const double l1 = __shfl(mc, n - 2), l2 = __shfl(mc, n - 3);
+                    const int nu = __builtin_amdgcn_readfirstlane(n);      // the row's knot count is wave-uniform: scalar lane reads, no ds_bpermute
+                    const double l1 = readlane_f64(mc, nu - 2), l2 = readlane_f64(mc, nu - 3);
                     const double em1 = 2.0 * m0 - m1, em2 = 2.0 * em1 - m0, en1 = 2.0 * l1 - l2, en = 2.0 * en1 - l1;
                     const double E = lane <= n - 2 ? mc : en1;
                     const double es1 = dpp0_f64<DPP_WAVE_SHR1>(E), es2 = dpp0_f64<DPP_WAVE_SHR1>(es1), el1 = dpp0_f64<DPP_WAVE_SHL1>(E);
