@@ -336,6 +336,9 @@ __global__ __launch_bounds__(64, (METHOD == IVS_LINEAR || METHOD == IVS_SLINEAR 
 #include "ivs_surface_masked_pass.hpp"      // the not-a-knot methods' row-pass form (needs the definitions above)
 namespace ivs {
 
+#ifndef IVS_MASKED_PASS_LOCAL
+#define IVS_MASKED_PASS_LOCAL 1      // pchip / akima with missing quotes on the two-pass layout too (0: the lane-per-knot kernel above)
+#endif
 #ifndef IVS_MASKED_PASS
 #define IVS_MASKED_PASS 1      // 0: cubic / cubicspline on the two-lanes-per-row kernel above (A/B)
 #endif
@@ -350,11 +353,14 @@ inline bool launch_surface_masked(const SurfaceParams& p, const LaunchCtx& cx) {
     int64_t grid = (int64_t)cx.num_cu * (lerp ? 12 : 8);
     const int64_t work = (p.B + 63) / 64;
     if (grid > work) grid = work;
-    if (p.method == IVS_QUADRATIC || (IVS_MASKED_PASS && (p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE))) {
+    if (p.method == IVS_QUADRATIC || (IVS_MASKED_PASS && (p.method == IVS_CUBIC || p.method == IVS_CUBICSPLINE)) ||
+        (IVS_MASKED_PASS_LOCAL && d_is_local(p.method))) {
         int64_t g12 = (int64_t)cx.num_cu * 12;
         if (g12 > work) g12 = work;
         if (p.method == IVS_CUBIC) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_CUBIC>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
         else if (p.method == IVS_QUADRATIC) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_QUADRATIC>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
+        else if (p.method == IVS_PCHIP) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_PCHIP>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
+        else if (p.method == IVS_AKIMA) hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_AKIMA>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
         else hipLaunchKernelGGL((surface_masked_pass_kernel<IVS_CUBICSPLINE>), dim3((unsigned)g12), dim3(64), masked_pass_lds_bytes(), cx.st, p);
         return true;
     }

@@ -157,11 +157,96 @@ __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, cons
     for (int k = 0; k < 8; ++k) if (i0 + k < n) xr[i0 + k] = rh[k];
 }
 
+// Local-slope methods (pchip, akima) on the same layout: lane = (row of the pass, segment of 8 compacted knots), the 8 slopes
+// of the segment from the 11 secants around it (2 knots of either neighbour), no system to solve.  Formulas of the
+// lane-per-knot form in ivs_surface_masked.hpp (pchip: weighted harmonic mean, one-sided three-point rule at knots 0 and
+// n - 1, the secant for n == 2; akima: secants extended linearly two steps beyond either end, the row maximum of
+// |m_{k+1} - m_k| + |m_{k-1} - m_{k-2}| over the row's 8 lanes by three DPP moves).  XS: strikes on entry, slopes on exit.
+template <int METHOD>
+__device__ __forceinline__ void masked_local8(const double* YC, double* XS, const int* NROW, int lane) {
+    constexpr bool AK = METHOD == IVS_AKIMA;
+    const int r = lane >> 3, seg = lane & 7, i0 = seg * 8;
+    const int n = NROW[r];
+    double* xr = XS + r * MK_RS;
+    const double* yr = YC + r * MK_RS;
+    auto cl = [&](int i) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
+    // secants F[i] and widths DX[i] of the intervals i0 - 2 + i, i = 0..10 (intervals outside [0, n-2]: 0 here, fixed up below)
+    double F[11], DX[11];
+    {
+        double xa = xr[cl(i0 - 2)], ya = yr[cl(i0 - 2)];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int idx = i0 - 2 + i;
+            const double xb = xr[cl(idx + 1)], yb = yr[cl(idx + 1)];
+            const bool in = idx >= 0 && idx <= n - 2;
+            const double dx = xb - xa;
+            DX[i] = in ? dx : 0.0;
+            F[i] = in ? (yb - ya) * refined_rcp(dx) : 0.0;
+            xa = xb; ya = yb;
+        }
+    }
+    double d[8];
+    if (AK) {
+        // linear extension: m_{-1} = 2 m_0 - m_1, m_{-2} = 2 m_{-1} - m_0; m_{n-1} = 2 m_{n-2} - m_{n-3}, m_n = 2 m_{n-1} - m_{n-2}
+        const double x3 = xr[n - 3], x2 = xr[n - 2], x1 = xr[n - 1], y3 = yr[n - 3], y2 = yr[n - 2], y1 = yr[n - 1];
+        const double mL1 = (y1 - y2) * refined_rcp(x1 - x2), mL2 = (y2 - y3) * refined_rcp(x2 - x3);      // m_{n-2}, m_{n-3}
+        const double en1 = 2.0 * mL1 - mL2, en = 2.0 * en1 - mL1;
+        const double m0 = (yr[1] - yr[0]) * refined_rcp(xr[1] - xr[0]), m1 = (yr[2] - yr[1]) * refined_rcp(xr[2] - xr[1]);
+        const double em1 = 2.0 * m0 - m1, em2 = 2.0 * em1 - m0;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int idx = i0 - 2 + i;
+            F[i] = idx == -1 ? em1 : (idx == -2 ? em2 : (idx == n - 1 ? en1 : (idx == n ? en : F[i])));
+        }
+        double fmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double f = akima_f12(F[k], F[k + 1], F[k + 2], F[k + 3]);
+            fmax = (i0 + k < n) ? __builtin_fmax(fmax, f) : fmax;
+        }
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP1>(fmax, fmax));
+        fmax = __builtin_fmax(fmax, dpp_f64<DPP_QUAD_SWAP2>(fmax, fmax));
+        fmax = __builtin_fmax(fmax, dpp_f64<0x141>(fmax, fmax));           // row_half_mirror: the other quad of the row's 8 lanes
+        const double thr = 1e-9 * fmax;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = akima_knot(F[k], F[k + 1], F[k + 2], F[k + 3], thr);
+    } else {
+        // the one-sided rule at knot n - 1 from the row's last three knots, once (n >= 3; n == 2: the secant)
+        double e_last = 0.0, m_only = 0.0;
+        {
+            const int a3 = n >= 3 ? n - 3 : 0, a2 = n >= 3 ? n - 2 : 0, a1 = n - 1;
+            const double x3 = xr[a3], x2 = xr[a2], x1 = xr[a1], y3 = yr[a3], y2 = yr[a2], y1 = yr[a1];
+            const double h0 = x1 - x2, h1 = x2 - x3;                                     // dx_{n-2}, dx_{n-3}
+            const double mp = (y1 - y2) * refined_rcp(h0), mpp = (y2 - y3) * refined_rcp(h1);
+            const double rs = refined_rcp(h0 + h1);
+            e_last = pchip_edge(mp, mpp, (2.0 * h0 + h1) * rs, h0 * rs);
+            m_only = (yr[n - 1] - yr[0]) * refined_rcp(xr[n - 1] - xr[0]);               // n == 2
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k;
+            // knot i: secants m_{i-1} = F[k+1], m_i = F[k+2]; widths dx_{i-1} = DX[k+1], dx_i = DX[k+2]
+            double v = pchip_knot(F[k + 1], F[k + 2], 2.0 * DX[k + 2] + DX[k + 1], DX[k + 2] + 2.0 * DX[k + 1]);
+            if (k == 0) {       // knot 0 sits in segment 0 only: h0 = dx_0, h1 = dx_1, secants m_0, m_1
+                const double h0 = DX[2], h1 = DX[3], rs = refined_rcp(h0 + h1);
+                const double e = pchip_edge(F[2], F[3], (2.0 * h0 + h1) * rs, h0 * rs);
+                v = seg == 0 ? e : v;
+            }
+            v = i == n - 1 ? e_last : v;
+            d[k] = n == 2 ? m_only : v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                               // every lane's strikes are in registers: the slopes may land
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (i0 + k < n) xr[i0 + k] = d[k];
+}
+
 template <int METHOD>
 __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParams p) {
-    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE || METHOD == IVS_QUADRATIC, "tridiagonal methods only");
+    static_assert(METHOD == IVS_CUBIC || METHOD == IVS_CUBICSPLINE || METHOD == IVS_QUADRATIC || d_is_local(METHOD), "tridiagonal and local-slope methods");
     constexpr bool QUAD = METHOD == IVS_QUADRATIC;
-    constexpr int MINROW = QUAD ? 3 : 4;
+    constexpr bool LOCAL = d_is_local(METHOD);
+    constexpr int MINROW = LOCAL ? (METHOD == IVS_AKIMA ? 3 : 2) : (QUAD ? 3 : 4);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int mT = p.mT, mK = p.mK;
@@ -257,7 +342,8 @@ __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParam
 #pragma unroll
                 for (int st = 4; st >= 1; st >>= 1) if (Ksh[jf + st] <= xq) jf += st;
             }
-            masked_solve8<QUAD>(YC, XS, NROW, lane);
+            if (LOCAL) masked_local8<METHOD>(YC, XS, NROW, lane);
+            else masked_solve8<QUAD>(YC, XS, NROW, lane);
             __syncthreads();
             // ---- strike evaluation of the pass's rows (q-lane): per row one RANK byte away from the full-grid interval
 #pragma unroll
