@@ -286,10 +286,15 @@ __device__ __forceinline__ double quad_knot(const XA& x, int n, int j) {      //
     return (x(j - 1) + x(j - 2)) / 2.0;                                       // mid_{j-2}
 }
 // the three quadratic B-splines that are non-zero on [t_ell, t_ell+1) at xv (de Boor's recurrence, scipy _deBoor_D)
+// (from the four knots t_{ell-1} .. t_{ell+2}; callers that hold the data sites in registers form the knots themselves)
+__device__ __forceinline__ void quad_basis_t(double tm1, double t0, double t1, double t2, double xv, double& h0, double& h1, double& h2);
 template <class XA>
 __device__ __forceinline__ void quad_basis(const XA& x, int n, int ell, double xv, double& h0, double& h1, double& h2) {
     const double tm1 = quad_knot(x, n, ell - 1), t0 = quad_knot(x, n, ell), t1 = quad_knot(x, n, ell + 1),
                  t2 = quad_knot(x, n, ell + 2);
+    quad_basis_t(tm1, t0, t1, t2, xv, h0, h1, h2);
+}
+__device__ __forceinline__ void quad_basis_t(double tm1, double t0, double t1, double t2, double xv, double& h0, double& h1, double& h2) {
     // the three divisions of _deBoor_D as reciprocal (<= 1 ulp) times numerator: a third of the instructions of the IEEE
     // division expansion, and this function runs per site AND per output value on the kernels whose rows have their own knots
     const double w = refined_rcp(t1 - t0);

@@ -65,15 +65,26 @@ __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, cons
             kl = ((n - 1) >> 3) == seg ? ((n - 1) & 7) : -1;
         }
     }
+    // QUAD: the data sites x(i-2 .. i+2) (clamped) and the values y(i .. i+2) roll along with the window, so the knots of the
+    // collocation row (midpoints of neighbouring sites, the triple end knots) come from registers -- quad_row read them from
+    // LDS again, eight loads with their clamps per site
+    double qa = xa, qb = xb, qc = xc, qd = xd, qe = xe, qy0 = yc, qy1 = yd, qy2 = ye;
+    const double x_first = xr[0], x_last = xr[n - 1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = i0 + k;
         const bool in = i < n;
         double a = dx2, b = 2.0 * (dx1 + dx2), c = dx1, rr = 3.0 * (dx2 * dl1 + dx1 * dl2);
         if (QUAD) {
-            const CView xv{xr, 1};
-            quad_row(xv, n, in ? i : 0, a, b, c);
-            rr = yr[in ? i : 0];
+            const double tA = i <= 2 ? x_first : (i >= n ? x_last : (qb + qa) / 2.0);              // t_i .. t_{i+3} (quad_knot)
+            const double tB = i + 1 <= 2 ? x_first : (i + 1 >= n ? x_last : (qc + qb) / 2.0);
+            const double tC = i + 2 <= 2 ? x_first : (i + 2 >= n ? x_last : (qd + qc) / 2.0);
+            const double tD = i + 3 >= n ? x_last : (qe + qd) / 2.0;
+            double lo, di, up;
+            quad_basis_t(tA, tB, tC, tD, qc, lo, di, up);
+            const bool interior = i > 0 && i < n - 1;              // rows 0 and n - 1: c_i = y_i
+            a = interior ? lo : 0.0; b = interior ? di : 1.0; c = interior ? up : 0.0;
+            rr = qy0;
         }
         const double rb = refined_rcp(b);
         double uu = c * rb, ll = a * rb, hh = rr * rb;
@@ -91,6 +102,7 @@ __device__ __forceinline__ void masked_solve8(const double* YC, double* XS, cons
             dx0 = dx1; dx1 = dx2; dx2 = dx3; dx3 = xn - xl;
             dl0 = dl1; dl1 = dl2; dl2 = dl3; dl3 = (yn - yl) * refined_rcp(dx3);
             xl = xn; yl = yn;
+            if (QUAD) { qa = qb; qb = qc; qc = qd; qd = qe; qe = xn; qy0 = qy1; qy1 = qy2; qy2 = yn; }
         }
     }
     // inclusive prefix products over the row's 8 segments: P_s = M_s P_{s - sh} (Kogge-Stone; a lane whose source would
