@@ -1031,6 +1031,13 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
     double* Tsh = sm + 8 * 72;
     double* TT = Tsh + 64;
     TqTables tt;
+    // the missing-quote probe's 64 row requests (below) go out FIRST: they fly while the T-phase runs
+    const bool probe = !NTR && !p.k_off && p.nK == DK && p.mK <= 64 && p.B >= 4096;
+    double q[64];
+    if (probe) {
+#pragma unroll
+        for (int s = 0; s < 64; ++s) q[s] = p.sigma[(int64_t)s * (p.B / 64) * (int64_t)(DT * DK) + (s & (DT - 1)) * DK + lane];
+    }
     dense_t_phase<METHOD, false, NTR>(p.T, p.Tq, p.mT, lane, Tsh, TT, nullptr, tt, p.nT, scratch);
     if (lane < DT) {
 #pragma unroll
@@ -1050,11 +1057,8 @@ __global__ __launch_bounds__(64) void tq_tables_kernel(SurfaceParams p, TqShared
     //     profiles/r03/nan/sparse_probe_rule.txt).  Several quotes missing per sampled row says the gaps cluster (illiquid strikes
     //     of SOME snapshots): the share of surfaces hit is then about the share of rows hit, and tagging stays cheaper.
     int mode = 0;
-    if (!NTR && !p.k_off && p.nK == DK && p.mK <= 64 && p.B >= 4096) {
+    if (probe) {
         int hit = 0, tot = 0;
-        double q[64];                                      // all 64 requests in flight before the first is looked at
-#pragma unroll
-        for (int s = 0; s < 64; ++s) q[s] = p.sigma[(int64_t)s * (p.B / 64) * (int64_t)(DT * DK) + (s & (DT - 1)) * DK + lane];
 #pragma unroll
         for (int s = 0; s < 64; ++s) {
             const int c = __popcll(__ballot(__builtin_isnan(q[s])));
