@@ -78,21 +78,23 @@ __device__ __forceinline__ double eval_linear_slopes(const XA& x, const YA& y, c
 }
 
 // One cubic-Hermite evaluation from knot slopes s (scipy PPoly coefficient build + Horner).
+__device__ __forceinline__ double hermite_eval(double x0, double x1, double y0, double y1, double s0, double s1, double xq) {
+    double h = x1 - x0;
+    double rh = refined_rcp(h);
+    double delta = (y1 - y0) * rh;
+    double t = (s0 + s1 - 2.0 * delta) * rh;
+    double c0 = t * rh;
+    double c1 = (delta - s0) * rh - t;
+    double u = xq - x0;
+    return ((c0 * u + c1) * u + s0) * u + y0;
+}
 template <class XA, class YA, class SA>
 __device__ __forceinline__ double eval_cubic(const XA& x, const YA& y, const SA& s, int n, int j, double xq,
                                              bool extrapolate_right) {
     if (j < 0) return qnan();
     if (!extrapolate_right && !(xq <= x(n - 1))) return qnan();
     int jj = j > n - 2 ? n - 2 : j;
-    double x0 = x(jj), y0 = y(jj), s0 = s(jj), s1 = s(jj + 1);
-    double h = x(jj + 1) - x0;
-    double rh = refined_rcp(h);
-    double delta = (y(jj + 1) - y0) * rh;
-    double t = (s0 + s1 - 2.0 * delta) * rh;
-    double c0 = t * rh;
-    double c1 = (delta - s0) * rh - t;
-    double u = xq - x0;
-    return ((c0 * u + c1) * u + s0) * u + y0;
+    return hermite_eval(x(jj), x(jj + 1), y(jj), y(jj + 1), s(jj), s(jj + 1), xq);
 }
 
 // Not-a-knot slopes by the Thomas recurrence, one thread per system (oracle nak_slopes()).

@@ -354,17 +354,61 @@ __global__ __launch_bounds__(64, 3) void surface_masked_pass_kernel(SurfaceParam
 #pragma unroll
                 for (int st = 4; st >= 1; st >>= 1) if (Ksh[jf + st] <= xq) jf += st;
             }
-            if (LOCAL) masked_local8<METHOD>(YC, XS, NROW, lane);
+#ifndef IVS_MP_ABL
+#define IVS_MP_ABL 0      // phase ablations (wrong results, timing only): 1 = no slope solve, 2 = no strike evaluation, 3 = no compaction tables
+#endif
+            if (IVS_MP_ABL == 1) {}
+            else if (LOCAL) masked_local8<METHOD>(YC, XS, NROW, lane);
             else masked_solve8<QUAD>(YC, XS, NROW, lane);
             __syncthreads();
             // ---- strike evaluation of the pass's rows (q-lane): per row one RANK byte away from the full-grid interval
 #pragma unroll
             for (int r = 0; r < MP_ROWS; ++r) {
-                const int n = NROW[r];
+                // the row's knot count and outermost strikes from its ballot mask (scalar: no LDS reads; the hull test of the
+                // methods that do not extrapolate cost two dependent LDS reads per row through the IDX table -- 0.6 of 7.0 ms)
+                const unsigned long long rm = vm[ps * MP_ROWS + r];
+                const int n = __popcll(rm);
+                const double x_last = readlane_f64(kx, 63 - __builtin_clzll(rm));
                 const int j = jf >= 0 ? (int)RANK[r * DK + jf] - 1 : -1;
                 const MaskedX X{Ksh, IDX + r * DK};
                 const CView Y{YC + r * MK_RS, 1}, S{XS + r * MK_RS, 1};
-                const double zz = QUAD ? eval_quadratic(X, S, n, j, xq) : eval_cubic(X, Y, S, n, j, xq, d_extrap_right(METHOD));
+                double zz;
+                if (IVS_MP_ABL == 2) zz = Y(lane & 7) + xq;
+                else if (QUAD) {
+                    // eval_quadratic with the row's strikes read ONCE: the six sites around the interval (x(je-2 .. je+3), je =
+                    // min(j, n-2)) hold every site the basis window [q, q+2], q in {je-1, je}, can ask for; the triple end knots
+                    // come from the ballot mask.  (eval_quadratic read ~11 strikes per row through the two-level IDX table:
+                    // the strike evaluation was 6.1 of the kernel's 11.4 ms.)  Same arithmetic: quad_knot / quad_basis_t.
+                    zz = nanv;
+                    if (j >= 0 && xq <= x_last) {
+                        const double x_first = readlane_f64(kx, __builtin_ctzll(rm));
+                        const int je = j > n - 2 ? n - 2 : j;
+                        auto cl = [&](int i) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
+                        double W[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) W[i] = X(cl(je - 2 + i));
+                        int q = je - 1 + ((xq >= (W[3] + W[2]) / 2.0) ? 1 : 0);
+                        q = j < n - 1 ? q : n - 3;
+                        q = q < 0 ? 0 : (q > n - 3 ? n - 3 : q);
+                        const bool hi = q == je;                                   // window x(q-1 .. q+3) = W[1..5], else W[0..4]
+                        const double xs0 = hi ? W[1] : W[0], xs1 = hi ? W[2] : W[1], xs2 = hi ? W[3] : W[2], xs3 = hi ? W[4] : W[3],
+                                     xs4 = hi ? W[5] : W[4];
+                        const double tm1 = q + 1 <= 2 ? x_first : (xs1 + xs0) / 2.0;             // t_{q+1} .. t_{q+4}
+                        const double t0 = q + 2 <= 2 ? x_first : (xs2 + xs1) / 2.0;
+                        const double t1 = q + 3 >= n ? x_last : (xs3 + xs2) / 2.0;
+                        const double t2 = q + 4 >= n ? x_last : (xs4 + xs3) / 2.0;
+                        double h0, h1, h2;
+                        quad_basis_t(tm1, t0, t1, t2, xq, h0, h1, h2);
+                        zz = h0 * S(q) + h1 * S(q + 1) + h2 * S(q + 2);
+                    }
+                }
+                else {
+                    zz = nanv;
+                    if (j >= 0 && (d_extrap_right(METHOD) || xq <= x_last)) {
+                        const int jj = j > n - 2 ? n - 2 : j;
+                        zz = hermite_eval(X(jj), X(jj + 1), Y(jj), Y(jj + 1), S(jj), S(jj + 1), xq);
+                    }
+                }
                 z[ps * MP_ROWS + r] = zz;
                 all_ok = all_ok && !__builtin_isnan(zz);
             }
