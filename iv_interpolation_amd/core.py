@@ -58,6 +58,11 @@ def _chan_kind(col: pd.Series, fill_method: bool = False) -> str:
     return "f32" if dt == np.float32 else "f64"
 
 
+# interpolate_batch takes the columnar path from this many frames on (1: interpolate_symbol too -- the path is the same code
+# for one frame, its vectorised bookkeeping replaces ~60 small pandas calls of the per-symbol bookkeeping)
+_COLUMNAR_MIN_FRAMES = 1
+
+
 def _concat_same_schema(frames, columns, dtypes) -> Optional[pd.DataFrame]:
     """``pd.concat(frames, ignore_index=True)`` for frames that share columns, dtypes AND block layout -- the callers' usual
     case: thousands of small frames cut from one query result -- or None when any frame differs (pd.concat decides then).
@@ -165,30 +170,38 @@ class HipBackend:
         from . import engine
         torch = engine.require_device()
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-        ko, qo = d(src_off), d(q_off)
-        pos_d = d(pos)
         total_q = int(total_q)
-        yk = d(np.stack(chan))
         fidx = gr = dts = kp = None
         if self.fused:
-            vall, g = valid, None
+            vall, sym_col = valid, -1
+            host = {"ko": src_off, "qo": q_off, "pos": pos, "yk": np.stack(chan)}
             if greek is not None:
                 gvalid, ksrc, rsrc, psrc = greek
                 nv = valid.shape[0]
                 vall = np.concatenate([valid, gvalid]) if nv else gvalid
-                g = ((nv, nv + 1, nv + 2), d(ksrc), d(rsrc), d(psrc))
-            i32 = lambda v: d(np.asarray(v, np.int32)) if len(v) else None  # noqa: E731
-            first_ns = needs = None; sym_col = -1
+                host.update(ksrc=ksrc, rsrc=rsrc, psrc=psrc)
+            if vall.shape[0]:
+                host["vall"] = vall
+            if len(f_rows):
+                host.update(fsrc=fsrc, f_rows=np.asarray(f_rows, np.int32))
+            if len(c_rows):
+                host.update(csrc=csrc, c_rows=np.asarray(c_rows, np.int32))
+            if len(host_rows):
+                host["host_rows"] = np.asarray(host_rows, np.int32)
             if rows_info is not None:
                 fns, nds, sym_row = rows_info
-                first_ns, needs = d(fns), d(np.ascontiguousarray(nds).astype(np.uint8))
+                host.update(first_ns=fns, needs=np.ascontiguousarray(nds).astype(np.uint8))
                 sym_col = -1 if sym_row is None else int(sym_row)
-            r = engine.frame_columns(pos_d, ko, qo, total_q, yk, code, d(vall) if vall.shape[0] else None,
-                                     d(fsrc) if len(f_rows) else None, i32(f_rows), d(csrc) if len(c_rows) else None, i32(c_rows),
-                                     i32(host_rows), first_ns, needs, sym_col, g)
+            dv = _upload(torch, host)
+            g = ((nv, nv + 1, nv + 2), dv["ksrc"], dv["rsrc"], dv["psrc"]) if greek is not None else None
+            ko, qo, pos_d, yk = dv["ko"], dv["qo"], dv["pos"], dv["yk"]
+            r = engine.frame_columns(pos_d, ko, qo, total_q, yk, code, dv.get("vall"), dv.get("fsrc"), dv.get("f_rows"),
+                                     dv.get("csrc"), dv.get("c_rows"), dv.get("host_rows"), dv.get("first_ns"), dv.get("needs"),
+                                     sym_col, g)
             out, st, F, Cc, gr, dts, kp = r["chan"], r["status"], r["F"], r["C"], r["greeks"], r["date_ns"], r["keep"]
             idx_rows = r["idx"]
         else:
+            ko, qo, pos_d, yk = d(src_off), d(q_off), d(pos), d(np.stack(chan))
             fidx = engine.ffill_index_batch(pos_d, ko, d(valid), qo, total_q) if valid.shape[0] else None
             xk = pos_d.to(torch.float64)
             if greek is not None:
@@ -233,6 +246,28 @@ class HipBackend:
                "date_ns": None if dates_h is None else dates_h.numpy(),
                "keep": None if keep_h is None else keep_h.numpy().view(np.bool_)}
         return res
+
+
+def _upload(torch, host):
+    """{name: host array} -> {name: device tensor}.  A small call (interpolate_symbol: one symbol) sends everything in ONE
+    blocking copy of a packed buffer and hands out views of it -- a dozen separate copies of a few hundred bytes cost ~15 us
+    each, a sixth of such a call; large calls copy array by array (packing would add a pass over tens of megabytes)."""
+    arrs = {k: np.ascontiguousarray(v) for k, v in host.items()}
+    if sum(a.nbytes for a in arrs.values()) >= (1 << 20):
+        return {k: torch.from_numpy(a).cuda() for k, a in arrs.items()}
+    offs, n = {}, 0
+    for k, a in arrs.items():
+        offs[k] = n
+        n += (a.nbytes + 15) & ~15
+    buf = np.empty(max(n, 16), np.uint8)
+    for k, a in arrs.items():
+        buf[offs[k]:offs[k] + a.nbytes] = a.reshape(-1).view(np.uint8)
+    dev = torch.from_numpy(buf).cuda()
+    out = {}
+    for k, a in arrs.items():
+        t = dev[offs[k]:offs[k] + a.nbytes]
+        out[k] = (t.view(getattr(torch, str(a.dtype))) if a.nbytes else torch.empty(0, dtype=getattr(torch, str(a.dtype)), device="cuda")).reshape(a.shape)
+    return out
 
 
 def _frame_columns_generic(be, pos, chan, src_off, q_off, total_q, code, valid, fsrc, f_rows, csrc, c_rows, host_rows, greek,
@@ -331,6 +366,11 @@ class IVInterpolator:
                 gc.enable()
         if fast is not None:
             return fast
+        return self._batch_per_symbol(frames)
+
+    def _batch_per_symbol(self, frames: Sequence[pd.DataFrame]) -> List[Optional[pd.DataFrame]]:
+        """The reference's bookkeeping statement by statement per frame (guards and their log lines included), the device
+        work of all frames in one round trip."""
         preps: List[Optional[_Prepared]] = []
         for f in frames:
             try:
@@ -392,7 +432,7 @@ class IVInterpolator:
         (views of the long result).  Only for the plain case -- at least 4 frames with identical columns and dtypes, a
         datetime64 date column, an implemented method; anything else (and any frame the long frame cannot represent
         exactly) goes through the per-symbol bookkeeping, which is the reference's contract statement by statement."""
-        if len(frames) < 4:
+        if len(frames) < _COLUMNAR_MIN_FRAMES:
             return None
         try:
             code = method_code(self.method)
@@ -410,7 +450,9 @@ class IVInterpolator:
         lens = np.array([len(f) for f in frames], np.int64)
         if int(lens.sum()) == 0:
             return None
-        data = _concat_same_schema(frames, c0, dt0)                      # one schema for all (dtype rules are per symbol)
+        # one schema for all (dtype rules are per symbol); a single frame is its own long frame (nothing below writes to it)
+        # (the bookkeeping below works on positions: the frame's own index is never looked at)
+        data = f0 if len(frames) == 1 else _concat_same_schema(frames, c0, dt0)
         if data is None:
             if any(list(f.dtypes) != dt0 for f in frames):
                 return None
@@ -426,12 +468,13 @@ class IVInterpolator:
         except Exception as e:                                           # anything unusual: the per-symbol bookkeeping decides
             logger.debug(f"columnar batch path declined: {e}")
             return None
-        redo = [i for i, r in enumerate(out) if r is NotImplemented]
+        # NotImplemented: a frame the long frame cannot represent exactly.  None: a guard or a failed solve -- the per-symbol
+        # bookkeeping says so on the logger like the reference does (core.py:27,38,50,77,84); those frames stop at its guards
+        redo = [i for i, r in enumerate(out) if r is NotImplemented or r is None]
         if redo:
-            keep_be, self_fast = self._backend, None
-            single = IVInterpolator(self.method, self.min_points, backend=keep_be, preserve_greeks=self.preserve_greeks)
-            for i in redo:
-                out[i] = single.interpolate_batch([frames[i]])[0]
+            again = self._batch_per_symbol([frames[i] for i in redo])
+            for i, r in zip(redo, again):
+                out[i] = r
         return out
 
     def interpolate_frame(self, data: pd.DataFrame) -> pd.DataFrame:
@@ -491,10 +534,11 @@ class IVInterpolator:
                 rows[lo_:hi_] = grp[np.argsort(d64[grp], kind="quicksort")]
             dn = d_ns[rows]
         S_all = int(n_grp)
-        empty = pd.DataFrame({c: pd.Series(dtype=(bool if c == "is_interpolated" else data[c].dtype if c in data.columns else "float64"))
-                              for c in out_cols})
+        def empty():                                                     # (built on demand: 0.7 ms of pandas per call otherwise)
+            return pd.DataFrame({c: pd.Series(dtype=(bool if c == "is_interpolated" else data[c].dtype if c in data.columns else "float64"))
+                                 for c in out_cols})
         if len(rows) == 0:
-            return [None] * S_all if split else empty
+            return [None] * S_all if split else empty()
         start = np.searchsorted(sc, np.arange(S_all), side="left")
         count = np.searchsorted(sc, np.arange(S_all), side="right") - start
         present = count > 0
@@ -509,7 +553,7 @@ class IVInterpolator:
         on = keep_sym[sc] & (rel % MINUTE_NS == 0)                        # off-lattice rows vanish (R6)
         ridx = np.flatnonzero(on)
         if len(ridx) == 0:
-            return [None] * S_all if split else empty
+            return [None] * S_all if split else empty()
         rsym = sc[ridx]; lat = rel[ridx] // MINUTE_NS
         # compact symbol numbering over the kept symbols
         kept = np.flatnonzero(keep_sym)

@@ -204,3 +204,22 @@ def test_batch_call_restores_the_collector_state():
         assert not gc.isenabled()                                        # a caller that had it off keeps it off
     finally:
         gc.enable()
+
+
+def test_guards_speak_on_the_logger_like_the_reference(caplog):
+    """core.py:27,38,50: every `None` comes with a line on the module's logger.  The columnar path decides silently, so the
+    frames it answers with None are handed to the per-symbol bookkeeping, which stops at the same guard and says why --
+    through interpolate_symbol (one frame) and through interpolate_batch (many)."""
+    import logging
+    from iv_interpolation_amd.frame_store import synthetic_symbol
+    iv = IVInterpolator("linear", backend=OracleBackend())
+    short = synthetic_symbol("s0", 5, seed=1)                            # 5 rows < min_points = 10
+    good = [synthetic_symbol(f"s{i}", 12, seed=i) for i in range(1, 5)]
+    with caplog.at_level(logging.WARNING, logger="interpolation.core"):
+        assert iv.interpolate_symbol(short) is None
+    assert any("Insufficient data points: 5 < 10" in r.getMessage() for r in caplog.records)
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="interpolation.core"):
+        res = iv.interpolate_batch(good[:2] + [short] + good[2:])
+    assert res[2] is None and all(r is not None for i, r in enumerate(res) if i != 2)
+    assert sum("Insufficient data points" in r.getMessage() for r in caplog.records) == 1
