@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
     __syncthreads();
     const int64_t s_first = s_edge[0], s_last = s_edge[1];
     const bool one_series = s_first == s_last;                 // block-uniform
+    const bool two_series = s_last == s_first + 1;             // the block straddles one series boundary: both are staged
     int64_t sr[E1_RPT]; double xq[E1_RPT]; bool active[E1_RPT];
 #pragma unroll
     for (int u = 0; u < E1_RPT; ++u) {
@@ -257,16 +258,24 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
     for (int c = 0; c < p.C; ++c) {
         const int64_t a1 = p.knot_off[s_first];
         const int n1 = p.wn[s_first * p.C + c];
-        const bool staged = one_series && n1 > 0 && n1 <= E1_STAGE;      // block-uniform
+        const int n2 = two_series ? p.wn[s_last * p.C + c] : 0;
+        // block-uniform.  (Round 3: a block that straddles ONE series boundary -- 27 % of the blocks at 3781 rows per series --
+        // stages both series back to back instead of searching the global arrays row by row.)
+        const bool staged = (one_series || two_series) && n1 + n2 > 0 && n1 + n2 <= E1_STAGE;
         if (staged) {
             const double* gx = p.wx + (int64_t)c * p.total_knots + a1;
             const double* gy = p.wy + (int64_t)c * p.total_knots + a1;
             const double* gs = p.ws + (int64_t)c * p.total_knots + a1;
+            const int64_t d2 = two_series ? p.knot_off[s_last] - a1 : 0;       // the second series' compacted knots start here
             __syncthreads();                                   // previous channel's readers are done
-            for (int i = tid; i < n1; i += 256) { sx[i] = gx[i]; sy[i] = gy[i]; if (cubic) ss[i] = gs[i]; }
+            for (int i = tid; i < n1 + n2; i += 256) {
+                const int64_t gi = i < n1 ? i : d2 + (i - n1);
+                sx[i] = gx[gi]; sy[i] = gy[gi]; if (cubic) ss[i] = gs[gi];
+            }
             __syncthreads();
             if (lerp_method) {     // np.interp's per-interval slope (dy/dx, IEEE division) once per knot instead of per row
-                for (int i = tid; i + 1 < n1; i += 256) ss[i] = (sy[i + 1] - sy[i]) / (sx[i + 1] - sx[i]);
+                for (int i = tid; i + 1 < n1 + n2; i += 256)
+                    if (i + 1 != n1) ss[i] = (sy[i + 1] - sy[i]) / (sx[i + 1] - sx[i]);      // (no interval across the two series)
                 __syncthreads();
             }
         }
@@ -274,13 +283,15 @@ __global__ __launch_bounds__(256) void interp1d_eval_kernel(Interp1dParams p) {
         for (int u = 0; u < E1_RPT; ++u) {
             const int64_t s = sr[u];
             const int64_t a = p.knot_off[s];
-            const int n = staged ? n1 : p.wn[s * p.C + c];
+            const bool second = two_series && s == s_last;
+            const int n = staged ? (second ? n2 : n1) : p.wn[s * p.C + c];
+            const int sb = second ? n1 : 0;                    // the series' first staged knot
             const double* gx = p.wx + (int64_t)c * p.total_knots + a;
             const double* gy = p.wy + (int64_t)c * p.total_knots + a;
             const double* gs = p.ws + (int64_t)c * p.total_knots + a;
             double r = qnan();
             if (active[u] && n > 0 && n >= minkn) {
-                CView x{staged ? sx : gx, 1}, y{staged ? sy : gy, 1}, sl{staged ? ss : gs, 1};
+                CView x{staged ? sx + sb : gx, 1}, y{staged ? sy + sb : gy, 1}, sl{staged ? ss + sb : gs, 1};
                 const int j = find_interval(x, n, xq[u]);
                 if (staged && lerp_method) r = eval_linear_slopes(x, y, sl, n, j, xq[u], method == IVS_LINEAR);
                 else r = eval_method(method, x, y, sl, n, j, xq[u]);
