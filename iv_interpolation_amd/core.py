@@ -429,9 +429,10 @@ class IVInterpolator:
     def _batch_via_frame(self, frames) -> Optional[List[Optional[pd.DataFrame]]]:
         """interpolate_batch through the columnar path: the frames become ONE long frame grouped by frame
         number, one pass of vectorised bookkeeping and one device round trip, the result is cut back into per-symbol frames
-        (views of the long result).  Only for the plain case -- at least 4 frames with identical columns and dtypes, a
-        datetime64 date column, an implemented method; anything else (and any frame the long frame cannot represent
-        exactly) goes through the per-symbol bookkeeping, which is the reference's contract statement by statement."""
+        (views of the long result).  Only for the plain case -- frames with identical columns and dtypes, a datetime64 date
+        column, an implemented method; anything else (and any frame the long frame cannot represent exactly, and every
+        frame whose answer is None: its log line) goes through the per-symbol bookkeeping, which is the reference's
+        contract statement by statement.  interpolate_symbol arrives here with one frame."""
         if len(frames) < _COLUMNAR_MIN_FRAMES:
             return None
         try:
