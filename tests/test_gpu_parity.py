@@ -307,6 +307,41 @@ def test_full_size_properties_1M(method):
     assert err <= (0.0 if method == "linear" else 1e-12), err
 
 
+@pytest.mark.parametrize("frac", [0.1, 0.005])
+@pytest.mark.parametrize("method", ["linear", "cubic", "pchip", "akima", "nearest", "quadratic"])
+def test_full_size_missing_quotes_1M(method, frac):
+    """BASELINE config 3 size with 10 % / 0.5 % of the quotes missing (both make the probe send the whole batch to the
+    compaction kernels first): (a) a sample of surfaces equals the oracle, status included; (b) affine equivariance
+    f(a*sigma + c) == a*f(sigma) + c with the same NaN pattern; (c) a surface processed in the 1M batch equals the same
+    surface processed in a small batch (below the probe's size: tag-and-redo order) to the parity tolerance."""
+    import torch
+    import c_oracle
+    from iv_interpolation_amd import engine, synth
+    B = 1_000_000
+    d = synth.torch_batch(B, 64, 16, seed=synth.BASE_SEED + 5)
+    g = torch.Generator(device="cuda"); g.manual_seed(123)
+    d["sigma"][torch.rand(d["sigma"].shape, generator=g, device="cuda") < frac] = float("nan")
+    Kq, Tq = synth.query_grids(64, 16)
+    ws = engine.surface_workspace(B, False)
+    out, st = engine.surface_batch(d["K"], d["T"], d["sigma"], dev(Kq), dev(Tq), method, workspace=ws)
+    torch.cuda.synchronize()
+    from iv_interpolation_amd import _lib
+    off = int(_lib.load().ivs_debug_mode_offset())
+    assert int(ws[off:off + 4].cpu().numpy().view(np.int32)[0]) == 1          # missing quotes first
+    idx = torch.arange(0, B, 9973, device="cuda")
+    Ks, Ss = d["K"][idx].cpu().numpy(), d["sigma"][idx].cpu().numpy()
+    ref, rst = c_oracle.load().surface_batch(Ks, d["T"].cpu().numpy(), Ss, Kq, Tq, METHODS[method])
+    assert np.array_equal(st[idx].cpu().numpy(), rst)
+    close(out[idx].cpu().numpy(), ref, method, f"1M missing {frac} sample {method}")
+    small, sst = engine.surface_batch(d["K"][idx].contiguous(), d["T"], d["sigma"][idx].contiguous(), dev(Kq), dev(Tq), method)
+    assert np.array_equal(sst.cpu().numpy(), rst)
+    close(small.cpu().numpy(), ref, method, f"the sample as a small batch {method}")
+    out2, st2 = engine.surface_batch(d["K"], d["T"], d["sigma"] * 2.0 + 0.25, dev(Kq), dev(Tq), method, workspace=ws)
+    assert bool((st2 == st).all()) and bool((torch.isnan(out2) == torch.isnan(out)).all())
+    err = float((out2 - (out * 2.0 + 0.25)).nan_to_num(nan=0.0).abs().max())
+    assert err < 1e-10, err
+
+
 @pytest.mark.parametrize("method", DENSE_METHODS)
 @pytest.mark.parametrize("nK", [4, 5, 15, 16, 17, 33, 48, 63, 65, 81, 100, 127, 128])
 def test_dense_var_uniform_strike_counts(method, nK):
