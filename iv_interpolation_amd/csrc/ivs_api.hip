@@ -313,7 +313,12 @@ int ivs_frame_columns_f64(const ivs_frame_args* a, void* workspace, size_t works
     f.first_ns = a->first_ns; f.needs = a->needs; f.sym_col = a->sym_col; f.date_ns = a->date_ns; f.keep = a->keep;
     f.g_strike = a->g_strike; f.g_rate = a->g_rate; f.g_put = a->g_put; f.strike_src = a->strike_src; f.rate_src = a->rate_src; f.put_src = a->put_src;
     f.ch_iv = a->ch_iv; f.ch_S = a->ch_underlying; f.ch_T = a->ch_ttm; f.greeks = a->greeks; f.greeks_stride = a->greeks_stride;
-    hipLaunchKernelGGL(ivs::frame_fused_kernel, dim3((unsigned)((a->total_queries + ivs::FR_ROWS - 1) / ivs::FR_ROWS)), dim3(256), 0, st, f, p);
+    const dim3 fgrid((unsigned)((a->total_queries + ivs::FR_ROWS - 1) / ivs::FR_ROWS));
+    switch (ivs::frame_method_class(p.method)) {
+        case 0: hipLaunchKernelGGL(ivs::frame_fused_kernel<0>, fgrid, dim3(256), 0, st, f, p); break;
+        case 1: hipLaunchKernelGGL(ivs::frame_fused_kernel<1>, fgrid, dim3(256), 0, st, f, p); break;
+        default: hipLaunchKernelGGL(ivs::frame_fused_kernel<2>, fgrid, dim3(256), 0, st, f, p); break;
+    }
     return check_launch("frame_fused_kernel");
 }
 

@@ -141,15 +141,18 @@ struct FrameShared {
 
 // one staged block.  WHOLE: every source row of the block's symbols is staged (flat copy of the compacted knot arrays, no
 // access outside LDS); !WHOLE: a window of the source rows, knots and fill sources outside it come from global memory
-template <bool WHOLE>
+// MC: method class, a compile-time cut of the method switch -- 0 = linear / slinear (np.interp slopes), 1 = the Hermite family
+// (cubic, cubicspline, pchip, akima: one eval_cubic), 2 = everything else (eval_method's full switch: nearest, zero,
+// quadratic, the polynomial forms, the fill methods).  One body for all methods was 26 k instructions, twelve copies of the switch.
+template <bool WHOLE, int MC>
 __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const Interp1dParams& p, FrameShared& sh, int64_t g0,
                                                    int64_t s_first, int nsym, int64_t W0, int64_t W1x) {
     const int tid = threadIdx.x;
     const int C = p.C, method = p.method;
     const int NS = (int)(W1x - W0);
     const double nanv = qnan();
-    const bool has_table = method_is_cubic(method) || method_is_poly(method);
-    const bool lerp_method = method == IVS_LINEAR || method == IVS_SLINEAR;
+    const bool has_table = MC == 1 || (MC == 2 && (method_is_cubic(method) || method_is_poly(method)));
+    constexpr bool lerp_method = MC == 0;
     const int minkn = method_min_knots(method);
 
     // ---- staging: per symbol scalars, then everything per source row of the window
@@ -303,6 +306,7 @@ __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const I
                             // the staged slope table holds np.interp's slopes; a knot in front of the window has none there
                             if (lerp_method) v = jc >= q0 ? eval_linear_slopes(x, y, sl, n, jc, xq, method == IVS_LINEAR)
                                                           : eval_linear(x, y, n, jc, xq, method == IVS_LINEAR);
+                            else if (MC == 1) v = eval_cubic(x, y, sl, n, jc, xq, method_extrapolates_right(method));
                             else v = eval_method(method, x, y, sl, n, jc, xq);
                         }
                         if (jc >= 0 && x(jc) == xq) v = y(jc);     // a knot of this channel keeps its source cell
@@ -401,6 +405,7 @@ __device__ __forceinline__ void frame_block_staged(const FrameParams& f, const I
     }
 }
 
+template <int MC>
 __global__ __launch_bounds__(256) void frame_fused_kernel(FrameParams f, Interp1dParams p) {
     __shared__ FrameShared sh;
     const int tid = threadIdx.x;
@@ -437,8 +442,11 @@ __global__ __launch_bounds__(256) void frame_fused_kernel(FrameParams f, Interp1
         }
         return;
     }
-    if (whole) frame_block_staged<true>(f, p, sh, g0, s_first, nsym, W0, W1x);
-    else frame_block_staged<false>(f, p, sh, g0, s_first, nsym, W0, W1x);
+    if (whole) frame_block_staged<true, MC>(f, p, sh, g0, s_first, nsym, W0, W1x);
+    else frame_block_staged<false, MC>(f, p, sh, g0, s_first, nsym, W0, W1x);
+}
+__host__ __device__ constexpr int frame_method_class(int m) {
+    return (m == IVS_LINEAR || m == IVS_SLINEAR) ? 0 : ((m == IVS_CUBIC || m == IVS_CUBICSPLINE || m == IVS_PCHIP || m == IVS_AKIMA) ? 1 : 2);
 }
 
 }  // namespace ivs
