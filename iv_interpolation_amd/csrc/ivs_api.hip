@@ -347,7 +347,7 @@ int ivs_mt19937_words_u32(uint32_t seed, uint32_t* words, int64_t n_words, void*
     if (n_words < 0) return fail(IVS_EINVAL, "ivs_mt19937_words_u32: negative size");
     if (n_words == 0) return IVS_OK;
     if (!words) return fail(IVS_EINVAL, "ivs_mt19937_words_u32: null pointer");
-    hipLaunchKernelGGL(ivs::mt19937_words_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), seed, words, n_words);
+    hipLaunchKernelGGL(ivs::mt19937_words_kernel, dim3(1), dim3(ivs::MT_THREADS), 0, static_cast<hipStream_t>(stream), seed, words, n_words);
     return check_launch("mt19937_words_kernel");
 }
 

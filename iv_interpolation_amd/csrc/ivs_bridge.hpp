@@ -3,8 +3,8 @@
 // The reference builds one synthetic candle per interpolated row from draws of NumPy's process-global legacy
 // generator (MT19937: uniform / normal / exponential), row after row, symbol after symbol.  Reproducing its numbers
 // therefore means reproducing that STREAM: the kernels below consume the same 32-bit words in the same order.
-//   mt19937_words_kernel      the raw stream of np.random.seed(seed): one workgroup, 624-word state in LDS,
-//                             regeneration in four dependent phases of <= 227 independent lanes
+//   mt19937_words_kernel      the raw stream of np.random.seed(seed): one workgroup, the 624-word state double-buffered in LDS,
+//                             a regeneration = one parallel step from the old state (round 3) and one barrier
 //   bridge_count_kernel       words drawn by every row (0 for skipped rows) + block-local exclusive scan
 //   bridge_scan_blocks_kernel exclusive scan of the block totals (one workgroup)
 //   bridge_accept_kernel /    trend_following only: the polar-method normal deviates have data-dependent stream
@@ -56,39 +56,44 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-__global__ __launch_bounds__(256) void mt19937_words_kernel(uint32_t seed, uint32_t* words, int64_t n) {
-    __shared__ uint32_t mt[MT_N];
+// The in-place recurrence mt[i] = mt[(i + 397) % 624] ^ twist(mt[i], mt[i + 1]) reads, for i >= 227, words it has just
+// written -- rounds 1-2 ran it as four dependent phases with a barrier between reading and writing each (nine barriers per
+// 624 words, 0.79 G words/s: barrier and LDS latency, nothing else; now 1.48 G words/s).  Substituting the earlier phases gives every new word
+// from OLD words only:
+//   i <  227:  new[i] = old[i + 397] ^ tw(old[i], old[i + 1])
+//   i <  454:  new[i] = old[i + 170] ^ tw(old[i - 227], old[i - 226]) ^ tw(old[i], old[i + 1])
+//   i <  623:  new[i] = old[i -  57] ^ tw(old[i - 454], old[i - 453]) ^ tw(old[i - 227], old[i - 226]) ^ tw(old[i], old[i + 1])
+//   i == 623:  new[623] = new[396] ^ tw(old[623], new[0]), both by the lines above
+// so a regeneration is ONE parallel step into the other of two LDS buffers and one barrier (checked against NumPy's stream in
+// Python before it went to the GPU, and by tests/test_bridge.py on it).
+constexpr int MT_THREADS = 640;            // one new word per thread: ten wavefronts share the CU's four SIMDs (the step is issue-bound)
+__global__ __launch_bounds__(MT_THREADS) void mt19937_words_kernel(uint32_t seed, uint32_t* words, int64_t n) {
+    __shared__ uint32_t mtb[2][MT_N];
     const int tid = threadIdx.x;
     if (tid == 0) {
         uint32_t s = seed;
-        for (int i = 0; i < MT_N; ++i) { mt[i] = s; s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1); }
+        for (int i = 0; i < MT_N; ++i) { mtb[0][i] = s; s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1); }
     }
     __syncthreads();
-    for (int64_t base = 0; base < n; base += MT_N) {
-        // phase A: i in [0, 227) reads only old words
-        uint32_t v = 0;
-        if (tid < MT_N - MT_M) v = mt[tid + MT_M] ^ mt_twist(mt[tid], mt[tid + 1]);
-        __syncthreads();
-        if (tid < MT_N - MT_M) mt[tid] = v;
-        __syncthreads();
-        // phase B: i in [227, 454) reads new[i-227] (phase A) and old[i], old[i+1]
-        const int ib = tid + (MT_N - MT_M);
-        if (tid < MT_N - MT_M) v = mt[ib - (MT_N - MT_M)] ^ mt_twist(mt[ib], mt[ib + 1]);
-        __syncthreads();
-        if (tid < MT_N - MT_M) mt[ib] = v;
-        __syncthreads();
-        // phase C: i in [454, 623) reads new[i-227] (phase B) and old[i], old[i+1]
-        const int ic = tid + 2 * (MT_N - MT_M);
-        if (ic < MT_N - 1) v = mt[ic - (MT_N - MT_M)] ^ mt_twist(mt[ic], mt[ic + 1]);
-        __syncthreads();
-        if (ic < MT_N - 1) mt[ic] = v;
-        __syncthreads();
-        // phase D: i = 623 reads new[396], old[623], new[0]
-        if (tid == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_twist(mt[MT_N - 1], mt[0]);
-        __syncthreads();
-        for (int i = tid; i < MT_N; i += 256)
-            if (base + i < n) words[base + i] = mt_temper(mt[i]);
-        __syncthreads();
+    int cur = 0;
+    for (int64_t base = 0; base < n; base += MT_N, cur ^= 1) {
+        const uint32_t* o = mtb[cur];
+        uint32_t* w = mtb[cur ^ 1];
+        const int i = tid;
+        if (i < MT_N) {
+            uint32_t v;
+            if (i < 227) v = o[i + 397] ^ mt_twist(o[i], o[i + 1]);
+            else if (i < 454) v = o[i + 170] ^ mt_twist(o[i - 227], o[i - 226]) ^ mt_twist(o[i], o[i + 1]);
+            else if (i < 623) v = o[i - 57] ^ mt_twist(o[i - 454], o[i - 453]) ^ mt_twist(o[i - 227], o[i - 226]) ^ mt_twist(o[i], o[i + 1]);
+            else {
+                const uint32_t n0 = o[397] ^ mt_twist(o[0], o[1]);
+                const uint32_t n396 = o[566] ^ mt_twist(o[169], o[170]) ^ mt_twist(o[396], o[397]);
+                v = n396 ^ mt_twist(o[623], n0);
+            }
+            w[i] = v;
+            if (base + i < n) words[base + i] = mt_temper(v);
+        }
+        __syncthreads();                                        // the new state is complete; the old buffer is free to be overwritten
     }
 }
 
