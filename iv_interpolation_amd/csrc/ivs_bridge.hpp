@@ -210,21 +210,26 @@ __global__ __launch_bounds__(64) void bridge_gauss_walk_kernel(BridgeParams p, i
     int64_t pos = 0;                                  // next draw, in doubles
     int64_t win_base = 0, win_end = 0;
     bool overflow = false;
-    auto accepted = [&](int64_t P) -> bool {          // uniform call
-        if (P + 1 >= nd) { overflow = true; return true; }
-        if (P >= win_end) {
-            win_base = P & ~(int64_t)3;                  // keeps the 4-byte loads below aligned
-            __syncthreads();
-            for (int i = lane * 4; i < GW_WIN; i += 256) {
-                uint32_t v = 0;
-                if (win_base + i + 3 < nd) v = *reinterpret_cast<const uint32_t*>(p.acc + win_base + i);
-                else for (int k = 0; k < 4; ++k) if (win_base + i + k < nd) v |= (uint32_t)p.acc[win_base + i + k] << (8 * k);
-                *reinterpret_cast<uint32_t*>(win + i) = v;
-            }
-            __syncthreads();
-            win_end = win_base + GW_WIN;
+    auto stage = [&](int64_t P) {                     // uniform call: the window of acceptance flags from position P on
+        win_base = P & ~(int64_t)3;                      // keeps the 4-byte loads below aligned
+        __syncthreads();
+        for (int i = lane * 4; i < GW_WIN; i += 256) {
+            uint32_t v = 0;
+            if (win_base + i + 3 < nd) v = *reinterpret_cast<const uint32_t*>(p.acc + win_base + i);
+            else for (int k = 0; k < 4; ++k) if (win_base + i + k < nd) v |= (uint32_t)p.acc[win_base + i + k] << (8 * k);
+            *reinterpret_cast<uint32_t*>(win + i) = v;
         }
-        return win[P - win_base] != 0;
+        __syncthreads();
+        win_end = win_base + GW_WIN;
+    };
+    int64_t mbase = -64;                              // the mask covers the positions [mbase, mbase + 64)
+    unsigned long long amask = 0ull;                  // bit i: an attempt at mbase + i is accepted (or runs off the stream: overflow)
+    auto load_mask = [&](int64_t P) {                 // uniform call
+        if (P + 64 > win_end) stage(P);
+        const int64_t q = P + lane;
+        const bool a = (q + 1 >= nd) || win[q - win_base] != 0;      // an attempt that would run off the stream counts as accepted: overflow
+        amask = __ballot(a);
+        mbase = P;
     };
     int64_t* gpos = reinterpret_cast<int64_t*>(p.gauss);
     int64_t* epos = reinterpret_cast<int64_t*>(p.expu);
@@ -243,8 +248,18 @@ __global__ __launch_bounds__(64) void bridge_gauss_walk_kernel(BridgeParams p, i
             int64_t g;
             if (has) { g = last == G_INITIAL ? G_INITIAL : (last | G_CACHED); has = false; }
             else {
-                while (!accepted(pos)) pos += 2;
-                g = pos; last = pos; pos += 2; has = true;
+                // next accepted attempt at or behind `pos`, attempts two doubles apart: the acceptance flags of 64 stream positions
+                // sit in one scalar mask (a ballot over the staged window), so an attempt costs a shift, a parity mask and a
+                // count-trailing-zeros -- not a dependent LDS byte read (rounds 1-2: ~390 cycles per row, 2.9 s per 15 M rows)
+                int64_t P = pos;
+                for (;;) {
+                    if (P < mbase || P >= mbase + 64) load_mask(P);
+                    const unsigned long long m = (amask >> (P - mbase)) & 0x5555555555555555ull;      // positions of P's parity
+                    if (m) { P += __builtin_ctzll(m); break; }
+                    P += ((mbase + 64 - P) + 1) & ~(int64_t)1;                                           // ... beyond the mask
+                }
+                if (P + 1 >= nd) overflow = true;
+                g = P; last = P; pos = P + 2; has = true;
             }
             int64_t e = -1;
             if ((em >> l) & 1ull) { e = pos; pos += 1; if (pos > nd) overflow = true; }
