@@ -239,31 +239,61 @@ __global__ __launch_bounds__(64) void bridge_gauss_walk_kernel(BridgeParams p, i
         const int64_t r = r0 + lane;
         const double base = r < p.total_rows ? p.price[r] : __builtin_nan("");
         const double vol = (p.volume && r < p.total_rows) ? p.volume[r] : 0.0;
-        unsigned long long vm = __ballot(row_valid(base));
-        const unsigned long long em = __ballot(p.volume == nullptr || vol_missing(vol));
-        int64_t my_g = 0, my_e = -1;
-        while (vm) {
-            const int l = __builtin_ctzll(vm);
-            vm &= vm - 1ull;
-            int64_t g;
-            if (has) { g = last == G_INITIAL ? G_INITIAL : (last | G_CACHED); has = false; }
-            else {
-                // next accepted attempt at or behind `pos`, attempts two doubles apart: the acceptance flags of 64 stream positions
-                // sit in one scalar mask (a ballot over the staged window), so an attempt costs a shift, a parity mask and a
-                // count-trailing-zeros -- not a dependent LDS byte read (rounds 1-2: ~390 cycles per row, 2.9 s per 15 M rows)
-                int64_t P = pos;
-                for (;;) {
-                    if (P < mbase || P >= mbase + 64) load_mask(P);
-                    const unsigned long long m = (amask >> (P - mbase)) & 0x5555555555555555ull;      // positions of P's parity
-                    if (m) { P += __builtin_ctzll(m); break; }
-                    P += ((mbase + 64 - P) + 1) & ~(int64_t)1;                                           // ... beyond the mask
-                }
-                if (P + 1 >= nd) overflow = true;
-                g = P; last = P; pos = P + 2; has = true;
+        // Valid rows alternate between SEARCH rows (a new attempt: the row's deviate is f*x2 of the next accepted attempt) and
+        // CACHED rows (f*x1 of the same attempt), so the order-dependent chain runs over PAIRS only:
+        //     P_k = next accepted attempt at or behind pos,   pos <- P_k + 2 + (exponentials drawn by the pair's two rows)
+        // -- a dozen scalar instructions per pair.  Which row is which, the pair's exponential count and, afterwards, every
+        // row's positions from its pair's P are lane-parallel.  (Rounds 1-2 walked row by row, ~60 instructions each with the
+        // per-lane selects in the loop: 2.9 s per 15 M rows; now 1.53 s.)
+        const unsigned long long vm = __ballot(row_valid(base));
+        const unsigned long long emv = __ballot(p.volume == nullptr || vol_missing(vol)) & vm;      // valid rows that draw an exponential
+        const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+        const bool v_l = (vm >> lane) & 1ull, e_l = (emv >> lane) & 1ull;
+        const int t0 = has ? 1 : 0;                                   // uniform: 1 = the next valid row takes a cached deviate
+        const bool cached_l = v_l && (((t0 + __popcll(vm & lt)) & 1) != 0);
+        const bool search_l = v_l && !cached_l;
+        const unsigned long long after = vm & ~le, before = vm & lt;
+        const int nl = after ? __builtin_ctzll(after) : 0, pl = before ? 63 - __builtin_clzll(before) : 0;
+        const bool partner_e = after != 0ull && ((emv >> nl) & 1ull);     // search row: its cached partner (next valid row, if in this group) draws too
+        unsigned long long S = __ballot(search_l);
+        const unsigned long long C0 = __ballot(search_l && e_l), C1 = __ballot(search_l && partner_e);
+        // a leading cached row (its search partner sat in an earlier group -- or before this call) draws its exponential first
+        const int64_t last_in = last, pos_in = pos;
+        if (t0 && vm) {
+            if ((emv >> __builtin_ctzll(vm)) & 1ull) { pos += 1; if (pos > nd) overflow = true; }
+        }
+        int p_lo = 0, p_hi = 0;                                       // P of the pair, deposited in the search row's lane
+        while (S) {
+            const int l = __builtin_ctzll(S);
+            S &= S - 1ull;
+            int64_t P = pos;
+            for (;;) {
+                if (P < mbase || P >= mbase + 64) load_mask(P);
+                const unsigned long long m = (amask >> (P - mbase)) & 0x5555555555555555ull;      // positions of P's parity
+                if (m) { P += __builtin_ctzll(m); break; }
+                P += ((mbase + 64 - P) + 1) & ~(int64_t)1;                                           // ... beyond the mask
             }
-            int64_t e = -1;
-            if ((em >> l) & 1ull) { e = pos; pos += 1; if (pos > nd) overflow = true; }
-            if (lane == l) { my_g = g; my_e = e; }
+            if (P + 1 >= nd) overflow = true;
+            p_lo = lane == l ? (int)(uint32_t)P : p_lo;
+            p_hi = lane == l ? (int)(uint32_t)((uint64_t)P >> 32) : p_hi;
+            const int c = (int)((C0 >> l) & 1ull) + (int)((C1 >> l) & 1ull);
+            last = P;
+            pos = P + 2 + c;
+            if (c && pos > nd) overflow = true;
+        }
+        has = ((t0 + __popcll(vm)) & 1) != 0;
+        // every row's positions from its pair's P
+        const int q_lo = __shfl(p_lo, pl), q_hi = __shfl(p_hi, pl);   // the previous valid row's deposit (a cached row's search partner)
+        const int64_t P_own = (int64_t)(((uint64_t)(uint32_t)p_hi << 32) | (uint32_t)p_lo);
+        const int64_t P_prev = (int64_t)(((uint64_t)(uint32_t)q_hi << 32) | (uint32_t)q_lo);
+        int64_t my_g = 0, my_e = -1;
+        if (search_l) { my_g = P_own; my_e = e_l ? P_own + 2 : -1; }
+        else if (cached_l && before != 0ull) {
+            my_g = P_prev | G_CACHED;
+            my_e = e_l ? P_prev + 2 + (int64_t)((emv >> pl) & 1ull) : -1;
+        } else if (cached_l) {                                        // the leading cached row
+            my_g = last_in == G_INITIAL ? G_INITIAL : (last_in | G_CACHED);
+            my_e = e_l ? pos_in : -1;
         }
         if (r < p.total_rows) { gpos[r] = my_g; epos[r] = my_e; }        // coalesced; rows that draw nothing are never read
     }
